@@ -1,0 +1,102 @@
+// Shared device helpers for the MI355X (gfx950 / CDNA4) kernels of the DG_AE hot path.
+// Wave = 64 lanes everywhere; MFMA = v_mfma_f32_16x16x4_f32 (exact f32, k-ordered fmaf chain).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MGV_OK 0
+#define MGV_EINVAL (-1)      // bad argument (null pointer, unsupported H, negative size)
+#define MGV_EUNSUPPORTED (-2)
+
+#define MGV_CHECK_ARG(cond) do { if (!(cond)) return MGV_EINVAL; } while (0)
+#define MGV_LAUNCH_RET() do { hipError_t e__ = hipGetLastError(); return e__ == hipSuccess ? MGV_OK : (int)e__; } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace mgv {
+
+constexpr int kWave = 64;
+constexpr int kThreads = 256;     // 4 waves, one per SIMD of a CU
+constexpr int kTileRows = 64;     // nodes per workgroup tile
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh through one exp; exact limits at +-inf, relative error ~1e-7 near 0 handled by the series
+__device__ __forceinline__ float tanhf_(float x) {
+    float ax = fabsf(x);
+    if (ax < 0.04f) { float x2 = x * x; return x * (1.0f - x2 * (1.0f / 3.0f) + x2 * x2 * (2.0f / 15.0f)); }
+    float e = __expf(-2.0f * ax);
+    float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// One 16-deep k-block of D(16x16) += X(16xK) * W(16xK)^T where both operands are row-major with k
+// contiguous.  Lane (r = lane&15, q = lane>>4) loads k = kb+4q..kb+4q+3 of its row of X and of its
+// row of W as one float4; the four MFMAs then each see the SAME k on the A and the B side (a
+// consistent permutation of k inside the block, which a dot product does not care about).
+__device__ __forceinline__ void mma_kblock(f32x4& acc, const float4& a, const float4& b) {
+    acc = mfma16(a.x, b.x, acc);
+    acc = mfma16(a.y, b.y, acc);
+    acc = mfma16(a.z, b.z, acc);
+    acc = mfma16(a.w, b.w, acc);
+}
+
+// sum over the `width` (power of two <= 64) consecutive lanes a lane's group consists of
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int m = WIDTH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int m = WIDTH / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+
+// block-wide sum for 256-thread blocks; result valid in thread 0 (and all of wave 0)
+__device__ __forceinline__ float block_sum_256(float v, float* red /* >= 4 floats of LDS */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 add4(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 fma4(float s, const float4& a, const float4& b) { return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w)); }
+__device__ __forceinline__ float4 scale4(float s, const float4& a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// How the 4 waves of a workgroup split a (64 rows) x (H hidden columns) output whose three GRU gate
+// column blocks must land in the same lane: waves go across hidden-column tiles first (so each wave
+// streams only its slice of the weights), then across row tiles.
+template <int H>
+struct WaveSplit {
+    static_assert(H % 16 == 0 && H >= 16 && H <= 128, "H must be a multiple of 16 in [16,128]");
+    static constexpr int HC = H / 16;                  // hidden column tiles
+    static constexpr int WPC = HC < 4 ? HC : 4;        // waves across column tiles
+    static constexpr int WPR = 4 / WPC;                // waves across row tiles
+    static constexpr int RTW = 4 / WPR;                // row tiles (of 16) per wave
+    static constexpr int HCW = HC / WPC;               // column tiles per wave
+    static constexpr int LD = H + 4;                   // padded LDS leading dimension (floats)
+    static constexpr int LPR = H / 4;                  // lanes per row when a row is read as float4s
+    static constexpr int GROUPS = kThreads / LPR;      // rows processed concurrently by the block
+};
+
+inline int grid_for(int64_t tiles, int per_cu) {
+    int64_t cap = 256LL * per_cu;
+    return (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);
+}
+
+}  // namespace mgv

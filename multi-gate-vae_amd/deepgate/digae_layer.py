@@ -1,0 +1,90 @@
+"""Structural encoder / decoder surface of the reference (`DG_VAE/deepgate/digae_layer.py:26-33,
+232-297`) on top of the HIP kernels.  Module and parameter names, shapes, construction order
+(hence seeded initialisation) and call signatures follow the reference, so its checkpoints load and
+`train.py` builds the encoder the same way; the arithmetic is `ops.StructEncoderFn`.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .arch.gcn_conv import AggConv
+from .graph_plan import GraphPlan
+
+MAX_FEATURE_CLASSES = 8
+
+
+def feature_classes(x):
+    """Distinct rows of the node-feature matrix and each node's row id.  The kernels add the GRU's
+    feature term as a per-class table (`W_ih[:, H:] x_c + b_ih`), exact for any x with few distinct
+    rows — the reference always feeds one-hot rows (dg_ae_model_aig.py:59)."""
+    rows, inv = torch.unique(x, dim=0, return_inverse=True)
+    if rows.shape[0] > MAX_FEATURE_CLASSES:
+        raise NotImplementedError('node features with more than %d distinct rows are not supported by the '
+                                  'HIP structural encoder (got %d)' % (MAX_FEATURE_CLASSES, rows.shape[0]))
+    return rows.to(torch.float32), inv.to(torch.uint8).contiguous()
+
+
+class DirectedInnerProductDecoder(nn.Module):
+    """sigma(<s[src], t[dst]>) per edge (digae_layer.py:26-33)."""
+
+    def forward(self, s, t, edge_index, sigmoid=True):
+        return ops.edge_dot(s, t, edge_index, sigmoid)
+
+    def forward_all(self, s, t, sigmoid=True):
+        # dense N x N scores: only sensible for tiny graphs; not on the training path
+        adj = ops.dense_scores(s, t)
+        return torch.sigmoid(adj) if sigmoid else adj
+
+
+class MultiGCNEncoder(nn.Module):
+    def __init__(self, num_rounds, dim_hidden, dim_feature, enable_reverse, layernorm):
+        super().__init__()
+        self.num_rounds = num_rounds
+        self.enable_reverse = True          # the reference forces this on (digae_layer.py:238)
+        self.layernorm = layernorm
+        self.dim_feature = dim_feature
+        self.dim_hidden = dim_hidden
+        self.aggr = AggConv(dim_hidden, dim_hidden)
+        self.update = nn.GRU(dim_hidden + dim_feature, dim_hidden)
+        self.aggr_r = AggConv(dim_hidden, dim_hidden)
+        self.update_r = nn.GRU(dim_hidden + dim_feature, dim_hidden)
+        if self.layernorm:
+            self.ln = nn.LayerNorm(dim_hidden)
+
+    def _composed(self, aggr, gru, feat_rows):
+        """Fold the per-edge message Linear into the GRU input projection (tiny weight-space
+        products; autograd differentiates them)."""
+        H = self.dim_hidden
+        w_ih = gru.weight_ih_l0
+        w_m = w_ih[:, :H]
+        Wc = w_m @ aggr.msg.weight
+        bc = w_m @ aggr.msg.bias
+        xtab = feat_rows @ w_ih[:, H:].t() + gru.bias_ih_l0
+        return xtab, Wc, bc, gru.weight_hh_l0, gru.bias_hh_l0
+
+    def forward(self, x, edge_index, plan=None, classes=None):
+        if x.shape[1] != self.dim_feature:
+            raise ValueError('expected %d node features, got %d' % (self.dim_feature, x.shape[1]))
+        if plan is None:
+            plan = GraphPlan(edge_index, x.shape[0])
+        rows, xcls = classes if classes is not None else feature_classes(x)
+        rows = rows.to(self.update.weight_ih_l0.device)
+        f = self._composed(self.aggr, self.update, rows)
+        r = self._composed(self.aggr_r, self.update_r, rows)
+        ln_w = self.ln.weight if self.layernorm else None
+        ln_b = self.ln.bias if self.layernorm else None
+        return ops.StructEncoderFn.apply(plan, xcls, self.num_rounds, *f, *r, ln_w, ln_b)
+
+
+class DirectMultiGCNEncoder(nn.Module):
+    def __init__(self, dim_feature=3, dim_hidden=128, s_rounds=1, t_rounds=1, enable_reverse=True, layernorm=False):
+        super().__init__()
+        self.source_conv = MultiGCNEncoder(s_rounds, dim_hidden, dim_feature, enable_reverse, layernorm)
+        self.target_conv = MultiGCNEncoder(t_rounds, dim_hidden, dim_feature, enable_reverse, layernorm)
+
+    def forward(self, s, t, edge_index, plan=None, classes=None):
+        if plan is None:
+            plan = GraphPlan(edge_index, s.shape[0])
+        cs = classes if classes is not None else feature_classes(s)
+        ct = cs if (classes is not None or t is s) else feature_classes(t)
+        return self.source_conv(s, edge_index, plan, cs), self.target_conv(t, edge_index, plan, ct)
