@@ -54,6 +54,105 @@ int mgv_struct_stage_bwd(int H, int64_t N, const float* h_in, const int32_t* nbr
                          const float* gy_agg, float* g_direct_out, float* g_agg_out, float* dWc, float* dbc,
                          float* dWhh, float* dbhh, float* dxtab, float* dln_w, float* dln_b, void* stream);
 
+/* ---- Linear over node rows (hs_linear dg_ae_model_aig.py:64, hs_decompose :109, fc_{s,t}_{mu,logstd}
+ * digvae_model.py:135-136, readout Linear layers mlp.py:29,38; also the dgrad with W^T):
+ *   Y[N][M] = [X1 | X2] W^T + b     (X2/K2 = NULL/0 unless a torch.cat of two inputs is fused, :64)
+ * K1+K2 multiple of 16 (<= 256), M in {16,32,64,128}; ld* = row strides in floats. */
+int mgv_linear_fwd(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
+                   const float* W, const float* b, int M, float* Y, int ldy, void* stream);
+/* dW[M][K1+K2] += dY^T [X1|X2],  db[M] += column sums of dY (db may be NULL) */
+int mgv_linear_wgrad(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
+                     const float* dY, int lddy, int M, float* dW, float* db, void* stream);
+/* agg[i] = sum_{j in nbr(i)} h[j], deg[i] = |nbr(i)| (deg may be NULL): the scatter-add half of
+ * MessagePassing.propagate as used by AggConv called on its own (gcn_conv.py:34) */
+int mgv_gather_sum(int H, int64_t N, const float* h, const int32_t* nbr_ptr, const int32_t* nbr_idx,
+                   float* agg, float* deg, void* stream);
+
+/* ---- levelised functional sweep (dg_ae_model_aig.py:70-97 and mig/xag/xmg siblings; arch/tfmlp.py:38-46;
+ * utils/dag_utils.py:91-105 is replaced by the tile tables).  T gate types ("slots"), per slot:
+ *   attn_u[T][2H] = Wk^T w_attn[H:],  Wvc[T][3H][2H] = W_ih Wv,  bvc[T][3H] = W_ih bv,  bih/bhh[T][3H].
+ * order/tile_* : updated nodes sorted by (level, slot) cut into <=64-node single-slot tiles;
+ * level_tile_ptr_host: HOST array [num_levels+1] of tile offsets.  hf must be zero on entry
+ * (num_rounds = 1: every node is updated once from h0 = 0). */
+int mgv_func_sweep_fwd(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                       const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
+                       const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src, const float* hs,
+                       float* hf, const float* attn_u, const float* Wvc, const float* bvc, const float* bih,
+                       const float* bhh, void* stream);
+/* backward sweep, levels in reverse.  ghf[N][H] = dL/dhf from the losses; ghs[N][H] is ADDED to;
+ * scratch: dzb[N][2H], alpha[E], dsc[E] (in-CSR edge order).  WvcT[T][2H][3H]. */
+int mgv_func_sweep_bwd(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                       const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
+                       const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src,
+                       const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_slot,
+                       const uint8_t* gslot, const float* hs, const float* hf, const float* attn_u,
+                       const float* Wvc, const float* WvcT, const float* bvc, const float* bih, const float* bhh,
+                       const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc, float* d_attn_u,
+                       float* dWvc, float* dbvc, float* dbih, float* dbhh, void* stream);
+
+/* ---- inner-product decoder and reconstruction loss (digae_layer.py:26-29, dg_ae_model_aig.py:108-130).
+ * s, t: row pointers with common row stride ld (the two halves of hs_decompose's output);
+ * edge lists are int64 like the reference's edge_index rows. */
+int mgv_edge_dot_fwd(int H, int64_t E, const float* s, const float* t, int ld, const int64_t* src,
+                     const int64_t* dst, int sigmoid, float* out, void* stream);
+int mgv_edge_dot_bwd(int H, int64_t E, const float* s, const float* t, int ld, const int64_t* src,
+                     const int64_t* dst, int sigmoid, const float* gout, float* ds, float* dt, void* stream);
+/* sums[0] += sum_pos -log(sigma+1e-15), sums[1] += sum_neg -log(1-sigma+1e-15); counts += {TP,FP,TN,FN}
+ * (trainer.py:240-244); pred_bin[Epos+Eneg] optional */
+int mgv_recon_loss_fwd(int H, const float* s, const float* t, int ld, const int64_t* pos_src, const int64_t* pos_dst,
+                       int64_t Epos, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
+                       double* sums, uint64_t* counts, int32_t* pred_bin, void* stream);
+/* ds/dt += dL/ds, dL/dt for loss = sums[0]/Epos + sums[1]/Eneg scaled by the DEVICE scalar *gscale */
+int mgv_recon_loss_bwd(int H, const float* s, const float* t, int ld, const int64_t* pos_src, const int64_t* pos_dst,
+                       int64_t Epos, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
+                       const float* gscale, float* ds, float* dt, void* stream);
+
+/* ---- functional-similarity loss (trainer.py:158-163, utils/utils.py:32-36): dis = 1 - cos(hf[a], hf[b]),
+ * L1 between the z-normalised dis and z-normalised tt.  ws[8] doubles (zeroed by the caller):
+ * 0 sum dis, 1 sum dis^2, 2 sum tt, 3 sum tt^2, 4 sum |zd-zt| (loss = ws[4]/P), 5-6 backward sums. */
+int mgv_func_loss_fwd(int H, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b,
+                      const float* tt, float eps, float* dis, double* ws, void* stream);
+int mgv_func_loss_bwd(int H, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b,
+                      const float* tt, const float* dis, float eps, const double* ws, const float* gscale,
+                      float* dhf, void* stream);
+
+/* ---- reparameterisation sampler + KL (digvae_model.py:134-142, trainer.py:146-147):
+ * z = mu + exp(logstd) * eps; eps given, or NULL = drawn from the counter-based generator (seed) and
+ * returned in eps_out; klsum += sum(1 + 2 logstd - mu^2 - exp(logstd)^2) */
+int mgv_reparam_fwd(int64_t n, const float* mu, const float* logstd, const float* eps, uint64_t seed,
+                    float* eps_out, float* z, double* klsum, void* stream);
+/* dmu = gz + *gkl*klcoef*(-2mu); dlogstd = gz*eps*exp(logstd) + *gkl*klcoef*(2-2exp(2logstd)); gz/gkl may be NULL */
+int mgv_reparam_bwd(int64_t n, const float* mu, const float* logstd, const float* eps, const float* gz,
+                    const float* gkl, float klcoef, float* dmu, float* dlogstd, void* stream);
+/* counts += {TP,FP,TN,FN} of pred_bin vs gt_bin (trainer.py:240-244) */
+int mgv_confusion(int64_t n, const int32_t* pred_bin, const int32_t* gt_bin, uint64_t* counts, void* stream);
+
+/* ---- readout MLP pieces (arch/mlp.py:27-47 = Linear, BatchNorm1d, ReLU, Dropout; dg_ae_model_aig.py:102-106)
+ * colstats: sums[c] += sum_i Y[i][c], sums[C+c] += sum_i Y[i][c]^2 (BatchNorm batch statistics) */
+int mgv_colstats(int64_t N, int C, const float* Y, int ld, double* sums, void* stream);
+/* A = dropout_p(relu(gamma*(Y-mean)*invstd+beta)); dropout mask from a counter-based hash of (seed, element) */
+int mgv_bn_act_fwd(int64_t N, int C, const float* Y, const float* mean, const float* invstd, const float* gamma,
+                   const float* beta, float p_drop, uint64_t seed, float* A, void* stream);
+/* dZ = dA * mask * [bn_out > 0]; sums[c] += sum dZ (= dbeta), sums[C+c] += sum dZ*xhat (= dgamma) */
+int mgv_bn_act_bwd(int64_t N, int C, const float* Y, const float* mean, const float* invstd, const float* gamma,
+                   const float* beta, float p_drop, uint64_t seed, const float* dA, float* dZ, double* sums, void* stream);
+/* dY = gamma*invstd*(dZ - [batch_stats](sums[c]/N + xhat*sums[C+c]/N)) */
+int mgv_bn_bwd_apply(int64_t N, int C, const float* Y, const float* mean, const float* invstd, const float* gamma,
+                     const float* dZ, const double* sums, int batch_stats, float* dY, void* stream);
+/* prob = A w + b (mlp.py:43, last Linear), clamped to [0,1] when clamp01 != 0 (dg_ae_model_aig.py:105) */
+int mgv_readout_head_fwd(int64_t N, int C, const float* A, const float* w, const float* b, int clamp01, float* prob, void* stream);
+/* given dprob[N]: dA = dy w, dw += sum dy A, db += sum dy with dy = dprob * [clamp inactive] */
+int mgv_readout_head_bwd(int64_t N, int C, const float* A, const float* w, const float* b, int clamp01, const float* dprob,
+                         float* dA, float* dw, float* db, void* stream);
+/* nn.L1Loss, reduction mean (trainer.py:71,156): sum += sum |x - target|;  dx = *gscale/n * sign(x - target) */
+int mgv_l1_loss_fwd(int64_t n, const float* x, const float* target, double* sum, void* stream);
+int mgv_l1_loss_bwd(int64_t n, const float* x, const float* target, const float* gscale, float* dx, void* stream);
+
+/* ---- Adam on a flat fp32 buffer (torch.optim.Adam as constructed at trainer.py:73); grad is multiplied
+ * by grad_scale first (1/world_size after an all-reduce sum) */
+int mgv_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, float grad_scale, int64_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

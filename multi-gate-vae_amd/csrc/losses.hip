@@ -1,0 +1,375 @@
+// Edge / pair reductions of the DG_AE train step: inner-product decoder, reconstruction loss with
+// confusion counters, functional-similarity loss (cosine distance -> z-normalisation -> L1),
+// reparameterisation sampler + KL.  All HBM/gather bound: H/4 lanes read one 4H-byte row as float4s,
+// reductions go wave -> block -> one double atomic per block.
+#include "mgv_common.h"
+#include "../../include/mgvae_hip.h"
+
+namespace mgv {
+
+__device__ __forceinline__ void atomic_add4(float* p, const float4& v) {
+    atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    // 64-lane shuffle reduction on the two 32-bit halves is not available for doubles: go through LDS
+    const int tid = threadIdx.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int s = kThreads / 2; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    return red[0];
+}
+
+// ---------------------------------------------------------------------------------- decoder / recon
+// one "item" = one edge handled by LPR lanes
+template <int H, bool BWD>
+__global__ __launch_bounds__(kThreads) void k_edge_dot(int64_t E, const float* s, const float* t, int ld,
+                                                       const int64_t* src, const int64_t* dst, int sigmoid,
+                                                       float* out, const float* gout, float* ds, float* dt) {
+    constexpr int LPR = H / 4, EPB = kThreads / LPR;
+    const int lr = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+    for (int64_t e0 = (int64_t)blockIdx.x * EPB; e0 < E; e0 += (int64_t)gridDim.x * EPB) {
+        const int64_t e = e0 + slot;
+        const bool ok = e < E;
+        float4 a = zero4(), b = zero4();
+        int64_t u = 0, v = 0;
+        if (ok) { u = src[e]; v = dst[e]; a = ld4(s + u * ld + 4 * lr); b = ld4(t + v * ld + 4 * lr); }
+        const float val = group_sum<LPR>(dot4(a, b));
+        if (!BWD) {
+            if (ok && lr == 0) out[e] = sigmoid ? sigmoidf_(val) : val;
+        } else if (ok) {
+            float c = gout[e];
+            if (sigmoid) { const float p = sigmoidf_(val); c *= p * (1.0f - p); }
+            atomic_add4(ds + u * ld + 4 * lr, scale4(c, b));
+            atomic_add4(dt + v * ld + 4 * lr, scale4(c, a));
+        }
+    }
+}
+
+struct ReconArgs {
+    const float* s; const float* t; int ld;
+    const int64_t* psrc; const int64_t* pdst; int64_t Ep;
+    const int64_t* nsrc; const int64_t* ndst; int64_t En;
+    double* sums;               // [2]: sum -log(p+eps) over positives, sum -log(1-p+eps) over negatives
+    unsigned long long* cnt;    // [4]: TP, FP, TN, FN
+    int32_t* pred_bin;          // [Ep+En] or null
+    const float* gscale;        // bwd: device scalar, upstream gradient of the loss
+    float* ds; float* dt;       // bwd accumulators (same ld)
+};
+
+template <int H, bool BWD>
+__global__ __launch_bounds__(kThreads) void k_recon(ReconArgs a) {
+    constexpr int LPR = H / 4, EPB = kThreads / LPR;
+    __shared__ double red[kThreads];
+    const int lr = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+    const int64_t E = a.Ep + a.En;
+    float lp = 0.f, ln = 0.f;
+    unsigned int tp = 0, fp = 0, tn = 0, fn = 0;
+    float g = 0.f;
+    if (BWD) g = *a.gscale;
+    const float wpos = BWD ? g / (float)a.Ep : 0.f, wneg = BWD ? g / (float)a.En : 0.f;
+    for (int64_t e0 = (int64_t)blockIdx.x * EPB; e0 < E; e0 += (int64_t)gridDim.x * EPB) {
+        const int64_t e = e0 + slot;
+        const bool ok = e < E;
+        const bool pos = e < a.Ep;
+        float4 x = zero4(), y = zero4();
+        int64_t u = 0, v = 0;
+        if (ok) {
+            u = pos ? a.psrc[e] : a.nsrc[e - a.Ep];
+            v = pos ? a.pdst[e] : a.ndst[e - a.Ep];
+            x = ld4(a.s + u * a.ld + 4 * lr);
+            y = ld4(a.t + v * a.ld + 4 * lr);
+        }
+        const float val = group_sum<LPR>(dot4(x, y));
+        const float p = sigmoidf_(val);
+        if (!BWD) {
+            if (ok && lr == 0) {
+                const bool hit = p > 0.5f;
+                if (pos) { lp -= logf(p + 1e-15f); tp += hit; fn += !hit; }
+                else     { ln -= logf((1.0f - p) + 1e-15f); fp += hit; tn += !hit; }
+                if (a.pred_bin) a.pred_bin[e] = hit ? 1 : 0;
+            }
+        } else if (ok) {
+            // d/dval of -log(p+eps) = -p(1-p)/(p+eps);  of -log(1-p+eps) = p(1-p)/(1-p+eps)
+            const float dp = p * (1.0f - p);
+            const float c = pos ? -wpos * dp / (p + 1e-15f) : wneg * dp / ((1.0f - p) + 1e-15f);
+            atomic_add4(a.ds + u * a.ld + 4 * lr, scale4(c, y));
+            atomic_add4(a.dt + v * a.ld + 4 * lr, scale4(c, x));
+        }
+    }
+    if (!BWD) {
+        const double sp = block_sum_d((double)lp, red);
+        const double sn = block_sum_d((double)ln, red);
+        const double c0 = block_sum_d((double)tp, red), c1 = block_sum_d((double)fp, red);
+        const double c2 = block_sum_d((double)tn, red), c3 = block_sum_d((double)fn, red);
+        if (threadIdx.x == 0) {
+            atomicAdd(a.sums + 0, sp); atomicAdd(a.sums + 1, sn);
+            atomicAdd(a.cnt + 0, (unsigned long long)c0); atomicAdd(a.cnt + 1, (unsigned long long)c1);
+            atomicAdd(a.cnt + 2, (unsigned long long)c2); atomicAdd(a.cnt + 3, (unsigned long long)c3);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- functional loss
+// ws (double[8]): 0 sum d, 1 sum d^2, 2 sum t, 3 sum t^2, 4 sum |zd - zt|, 5 sum sgn, 6 sum sgn*zd
+template <int H>
+__global__ __launch_bounds__(kThreads) void k_func_dist(int64_t P, const float* hf, const int64_t* pa, const int64_t* pb,
+                                                        const float* tt, float eps, float* dis, double* ws) {
+    constexpr int LPR = H / 4, PPB = kThreads / LPR;
+    __shared__ double red[kThreads];
+    const int lr = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+    double sd = 0, sd2 = 0, st = 0, st2 = 0;
+    for (int64_t p0 = (int64_t)blockIdx.x * PPB; p0 < P; p0 += (int64_t)gridDim.x * PPB) {
+        const int64_t p = p0 + slot;
+        const bool ok = p < P;
+        float4 x = zero4(), y = zero4();
+        if (ok) { x = ld4(hf + pa[p] * H + 4 * lr); y = ld4(hf + pb[p] * H + 4 * lr); }
+        const float xy = group_sum<LPR>(dot4(x, y));
+        const float xx = group_sum<LPR>(dot4(x, x));
+        const float yy = group_sum<LPR>(dot4(y, y));
+        if (ok && lr == 0) {
+            const float nx = fmaxf(sqrtf(xx), eps), ny = fmaxf(sqrtf(yy), eps);
+            const float d = 1.0f - xy / (nx * ny);
+            dis[p] = d;
+            const float t = tt[p];
+            sd += d; sd2 += (double)d * d; st += t; st2 += (double)t * t;
+        }
+    }
+    sd = block_sum_d(sd, red); sd2 = block_sum_d(sd2, red); st = block_sum_d(st, red); st2 = block_sum_d(st2, red);
+    if (threadIdx.x == 0) { atomicAdd(ws + 0, sd); atomicAdd(ws + 1, sd2); atomicAdd(ws + 2, st); atomicAdd(ws + 3, st2); }
+}
+
+struct ZStats { float mu_d, inv_sd, mu_t, inv_st; };
+__device__ __forceinline__ ZStats zstats(const double* ws, int64_t P) {
+    // torch.std: unbiased (divide by P-1), utils/utils.py:32-36
+    const double n = (double)P;
+    const double md = ws[0] / n, mt = ws[2] / n;
+    const double vd = (ws[1] - n * md * md) / (n - 1.0), vt = (ws[3] - n * mt * mt) / (n - 1.0);
+    ZStats z;
+    z.mu_d = (float)md; z.mu_t = (float)mt;
+    z.inv_sd = (float)(1.0 / sqrt(vd > 0 ? vd : 0.0));
+    z.inv_st = (float)(1.0 / sqrt(vt > 0 ? vt : 0.0));
+    return z;
+}
+
+__global__ __launch_bounds__(kThreads) void k_func_l1(int64_t P, const float* dis, const float* tt, double* ws) {
+    __shared__ double red[kThreads];
+    const ZStats z = zstats(ws, P);
+    double sl = 0, ss = 0, ssz = 0;
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < P; p += (int64_t)gridDim.x * kThreads) {
+        const float zd = (dis[p] - z.mu_d) * z.inv_sd, zt = (tt[p] - z.mu_t) * z.inv_st;
+        const float diff = zd - zt;
+        const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        sl += fabsf(diff); ss += sg; ssz += (double)sg * zd;
+    }
+    sl = block_sum_d(sl, red); ss = block_sum_d(ss, red); ssz = block_sum_d(ssz, red);
+    if (threadIdx.x == 0) { atomicAdd(ws + 4, sl); atomicAdd(ws + 5, ss); atomicAdd(ws + 6, ssz); }
+}
+
+// dL/dd_q = g/(P sd) [sgn_q - mean(sgn) - zd_q * sum(sgn*zd)/(P-1)];  d = 1 - cos
+template <int H>
+__global__ __launch_bounds__(kThreads) void k_func_bwd(int64_t P, const float* hf, const int64_t* pa, const int64_t* pb,
+                                                       const float* tt, const float* dis, float eps, const double* ws,
+                                                       const float* gscale, float* dhf) {
+    constexpr int LPR = H / 4, PPB = kThreads / LPR;
+    const int lr = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+    const ZStats z = zstats(ws, P);
+    const float g = *gscale;
+    const float mean_s = (float)(ws[5] / (double)P), ssz = (float)(ws[6] / ((double)P - 1.0));
+    const float k = g / (float)P * z.inv_sd;
+    for (int64_t p0 = (int64_t)blockIdx.x * PPB; p0 < P; p0 += (int64_t)gridDim.x * PPB) {
+        const int64_t p = p0 + slot;
+        const bool ok = p < P;
+        float4 x = zero4(), y = zero4();
+        int64_t ia = 0, ib = 0;
+        if (ok) { ia = pa[p]; ib = pb[p]; x = ld4(hf + ia * H + 4 * lr); y = ld4(hf + ib * H + 4 * lr); }
+        const float xy = group_sum<LPR>(dot4(x, y));
+        const float xx = group_sum<LPR>(dot4(x, x));
+        const float yy = group_sum<LPR>(dot4(y, y));
+        if (!ok) continue;
+        const float zd = (dis[p] - z.mu_d) * z.inv_sd, zt = (tt[p] - z.mu_t) * z.inv_st;
+        const float diff = zd - zt;
+        const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+        const float dd = k * (sg - mean_s - zd * ssz);      // dL/d dis
+        const float dc = -dd;                               // dL/d cos
+        const float rx = sqrtf(xx), ry = sqrtf(yy);
+        const float nx = fmaxf(rx, eps), ny = fmaxf(ry, eps);
+        const float inv = 1.0f / (nx * ny);
+        const float cs = xy * inv;
+        // cos = <x,y>/(nx ny); the norm factor only depends on x where it is not clamped
+        const float kx = rx > eps ? cs / (nx * nx) : 0.f, ky = ry > eps ? cs / (ny * ny) : 0.f;
+        const float4 gx = make_float4(dc * (y.x * inv - kx * x.x), dc * (y.y * inv - kx * x.y), dc * (y.z * inv - kx * x.z), dc * (y.w * inv - kx * x.w));
+        const float4 gy = make_float4(dc * (x.x * inv - ky * y.x), dc * (x.y * inv - ky * y.y), dc * (x.z * inv - ky * y.z), dc * (x.w * inv - ky * y.w));
+        atomic_add4(dhf + ia * H + 4 * lr, gx);
+        atomic_add4(dhf + ib * H + 4 * lr, gy);
+    }
+}
+
+// ---------------------------------------------------------------------------------- sampler + KL
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ float gauss_from_counter(uint64_t seed, uint64_t i) {
+    const uint32_t a = mix32(seed * 0x9E3779B97F4A7C15ULL + 2 * i), b = mix32(seed * 0x9E3779B97F4A7C15ULL + 2 * i + 1);
+    const float u1 = ((a >> 8) + 1.0f) * (1.0f / 16777216.0f), u2 = (b >> 8) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * __cosf(6.283185307179586f * u2);
+}
+
+// z = mu + exp(logstd) * eps;  klsum += sum(1 + 2 logstd - mu^2 - exp(logstd)^2)
+__global__ __launch_bounds__(kThreads) void k_reparam_fwd(int64_t n, const float* mu, const float* ls, const float* eps,
+                                                          uint64_t seed, float* eps_out, float* z, double* klsum) {
+    __shared__ double red[kThreads];
+    double acc = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const float m = mu[i], l = ls[i];
+        const float e = eps ? eps[i] : gauss_from_counter(seed, (uint64_t)i);
+        if (eps_out) eps_out[i] = e;
+        const float sd = expf(l);
+        z[i] = m + sd * e;
+        acc += (double)(1.0f + 2.0f * l - m * m - sd * sd);
+    }
+    acc = block_sum_d(acc, red);
+    if (threadIdx.x == 0) atomicAdd(klsum, acc);
+}
+
+// dmu = gz + gkl * klcoef * (-2 mu);  dls = gz * eps * exp(ls) + gkl * klcoef * (2 - 2 exp(2 ls))
+__global__ __launch_bounds__(kThreads) void k_reparam_bwd(int64_t n, const float* mu, const float* ls, const float* eps,
+                                                          const float* gz, const float* gkl, float klcoef, float* dmu, float* dls) {
+    const float gk = gkl ? (*gkl) * klcoef : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const float m = mu[i], l = ls[i], sd = expf(l);
+        const float g = gz ? gz[i] : 0.f;
+        dmu[i] = g + gk * (-2.0f * m);
+        dls[i] = g * eps[i] * sd + gk * (2.0f - 2.0f * sd * sd);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_confusion(int64_t n, const int32_t* pred, const int32_t* gt, unsigned long long* cnt) {
+    __shared__ double red[kThreads];
+    unsigned int tp = 0, fp = 0, tn = 0, fn = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const int p = pred[i], g = gt[i];
+        tp += (p == 1) & (g == 1); fp += (p == 1) & (g == 0); tn += (p == 0) & (g == 0); fn += (p == 0) & (g == 1);
+    }
+    const double c0 = block_sum_d((double)tp, red), c1 = block_sum_d((double)fp, red);
+    const double c2 = block_sum_d((double)tn, red), c3 = block_sum_d((double)fn, red);
+    if (threadIdx.x == 0) {
+        atomicAdd(cnt + 0, (unsigned long long)c0); atomicAdd(cnt + 1, (unsigned long long)c1);
+        atomicAdd(cnt + 2, (unsigned long long)c2); atomicAdd(cnt + 3, (unsigned long long)c3);
+    }
+}
+
+inline int items_grid(int64_t items, int per_block) { return grid_for((items + per_block - 1) / per_block, 8); }
+
+}  // namespace mgv
+
+#define MGV_DISPATCH_H(H, CALL)                      \
+    switch (H) {                                     \
+        case 16: { constexpr int HH = 16; CALL; } break;  \
+        case 32: { constexpr int HH = 32; CALL; } break;  \
+        case 64: { constexpr int HH = 64; CALL; } break;  \
+        case 128: { constexpr int HH = 128; CALL; } break; \
+        default: return MGV_EUNSUPPORTED;            \
+    }
+
+extern "C" int mgv_edge_dot_fwd(int H, int64_t E, const float* s, const float* t, int ld, const int64_t* src,
+                                const int64_t* dst, int sigmoid, float* out, void* stream) {
+    MGV_CHECK_ARG(E >= 0 && s && t && out && ld >= H && ld % 4 == 0);
+    if (E == 0) return MGV_OK;
+    MGV_CHECK_ARG(src && dst);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_edge_dot<HH, false>), dim3(mgv::items_grid(E, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st,
+                                         E, s, t, ld, src, dst, sigmoid, out, nullptr, nullptr, nullptr));
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_edge_dot_bwd(int H, int64_t E, const float* s, const float* t, int ld, const int64_t* src,
+                                const int64_t* dst, int sigmoid, const float* gout, float* ds, float* dt, void* stream) {
+    MGV_CHECK_ARG(E >= 0 && s && t && gout && ds && dt && ld >= H && ld % 4 == 0);
+    if (E == 0) return MGV_OK;
+    MGV_CHECK_ARG(src && dst);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_edge_dot<HH, true>), dim3(mgv::items_grid(E, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st,
+                                         E, s, t, ld, src, dst, sigmoid, nullptr, gout, ds, dt));
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_recon_loss_fwd(int H, const float* s, const float* t, int ld, const int64_t* pos_src, const int64_t* pos_dst,
+                                  int64_t Epos, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
+                                  double* sums, uint64_t* counts, int32_t* pred_bin, void* stream) {
+    MGV_CHECK_ARG(s && t && sums && counts && Epos >= 0 && Eneg >= 0 && ld >= H && ld % 4 == 0);
+    MGV_CHECK_ARG((Epos == 0 || (pos_src && pos_dst)) && (Eneg == 0 || (neg_src && neg_dst)));
+    if (Epos + Eneg == 0) return MGV_OK;
+    mgv::ReconArgs a{};
+    a.s = s; a.t = t; a.ld = ld; a.psrc = pos_src; a.pdst = pos_dst; a.Ep = Epos; a.nsrc = neg_src; a.ndst = neg_dst; a.En = Eneg;
+    a.sums = sums; a.cnt = reinterpret_cast<unsigned long long*>(counts); a.pred_bin = pred_bin;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_recon<HH, false>), dim3(mgv::items_grid(Epos + Eneg, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st, a));
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_recon_loss_bwd(int H, const float* s, const float* t, int ld, const int64_t* pos_src, const int64_t* pos_dst,
+                                  int64_t Epos, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
+                                  const float* gscale, float* ds, float* dt, void* stream) {
+    MGV_CHECK_ARG(s && t && gscale && ds && dt && Epos >= 0 && Eneg >= 0 && ld >= H && ld % 4 == 0);
+    MGV_CHECK_ARG((Epos == 0 || (pos_src && pos_dst)) && (Eneg == 0 || (neg_src && neg_dst)));
+    if (Epos + Eneg == 0) return MGV_OK;
+    mgv::ReconArgs a{};
+    a.s = s; a.t = t; a.ld = ld; a.psrc = pos_src; a.pdst = pos_dst; a.Ep = Epos; a.nsrc = neg_src; a.ndst = neg_dst; a.En = Eneg;
+    a.gscale = gscale; a.ds = ds; a.dt = dt;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_recon<HH, true>), dim3(mgv::items_grid(Epos + Eneg, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st, a));
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_func_loss_fwd(int H, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b,
+                                 const float* tt, float eps, float* dis, double* ws, void* stream) {
+    MGV_CHECK_ARG(P >= 2 && hf && pair_a && pair_b && tt && dis && ws);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_func_dist<HH>), dim3(mgv::items_grid(P, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st,
+                                         P, hf, pair_a, pair_b, tt, eps, dis, ws));
+    hipLaunchKernelGGL(mgv::k_func_l1, dim3(mgv::items_grid(P, mgv::kThreads)), dim3(mgv::kThreads), 0, st, P, dis, tt, ws);
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_func_loss_bwd(int H, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b,
+                                 const float* tt, const float* dis, float eps, const double* ws, const float* gscale,
+                                 float* dhf, void* stream) {
+    MGV_CHECK_ARG(P >= 2 && hf && pair_a && pair_b && tt && dis && ws && gscale && dhf);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_func_bwd<HH>), dim3(mgv::items_grid(P, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st,
+                                         P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, dhf));
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_reparam_fwd(int64_t n, const float* mu, const float* logstd, const float* eps, uint64_t seed,
+                               float* eps_out, float* z, double* klsum, void* stream) {
+    MGV_CHECK_ARG(n >= 0 && mu && logstd && z && klsum);
+    if (n == 0) return MGV_OK;
+    hipLaunchKernelGGL(mgv::k_reparam_fwd, dim3(mgv::items_grid(n, mgv::kThreads)), dim3(mgv::kThreads), 0,
+                       static_cast<hipStream_t>(stream), n, mu, logstd, eps, seed, eps_out, z, klsum);
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_reparam_bwd(int64_t n, const float* mu, const float* logstd, const float* eps, const float* gz,
+                               const float* gkl, float klcoef, float* dmu, float* dlogstd, void* stream) {
+    MGV_CHECK_ARG(n >= 0 && mu && logstd && eps && dmu && dlogstd);
+    if (n == 0) return MGV_OK;
+    hipLaunchKernelGGL(mgv::k_reparam_bwd, dim3(mgv::items_grid(n, mgv::kThreads)), dim3(mgv::kThreads), 0,
+                       static_cast<hipStream_t>(stream), n, mu, logstd, eps, gz, gkl, klcoef, dmu, dlogstd);
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_confusion(int64_t n, const int32_t* pred_bin, const int32_t* gt_bin, uint64_t* counts, void* stream) {
+    MGV_CHECK_ARG(n >= 0 && counts);
+    if (n == 0) return MGV_OK;
+    MGV_CHECK_ARG(pred_bin && gt_bin);
+    hipLaunchKernelGGL(mgv::k_confusion, dim3(mgv::items_grid(n, mgv::kThreads)), dim3(mgv::kThreads), 0,
+                       static_cast<hipStream_t>(stream), n, pred_bin, gt_bin, reinterpret_cast<unsigned long long*>(counts));
+    MGV_LAUNCH_RET();
+}

@@ -4,7 +4,7 @@ There is deliberately NO fallback: if the library is missing or a launcher repor
 caller gets an exception.  Argument types are read from the header itself, so the Python side
 cannot drift from the declared ABI.
 """
-import ctypes
+import ctypes  # noqa: F401 (re-exported for callers that build host arrays)
 import os
 import re
 

@@ -1,0 +1,102 @@
+"""Shared implementation of the four reference `Model` classes
+(DG_VAE/deepgate/dg_ae_model_{aig,mig,xag,xmg}.py): structural encoding -> hs_linear -> levelised
+per-gate-type attention + GRU sweep -> (hs, hf); readout, reconstruction loss, checkpoint loading.
+Sub-module names and construction order follow the reference so state_dicts and seeded
+initialisation line up."""
+import os
+
+import torch
+from torch import nn
+
+from . import ops
+from .arch.mlp import MLP
+from .arch.tfmlp import TFMlpAggr
+from .data import plan_of
+from .digae_layer import DirectedInnerProductDecoder
+from .sampling import negative_sampling
+
+EPS = 1e-15
+MAX_LOGSTD = 10
+
+
+class FunctionalModel(nn.Module):
+    ENCODER_ATTR = 'struct_encoder'
+    GATES = ()            # ((name, gate id), ...) in the order the reference creates aggr_*/update_* modules
+
+    def __init__(self, struct_encoder, num_rounds=1, dim_hidden=128, enable_encode=True, enable_reverse=True):
+        super().__init__()
+        setattr(self, self.ENCODER_ATTR, struct_encoder)
+        self.decoder = DirectedInnerProductDecoder()
+        self.hs_linear = nn.Linear(dim_hidden * 2, dim_hidden)
+        self.hs_decompose = nn.Linear(dim_hidden, dim_hidden * 2)
+        self.num_rounds = num_rounds
+        self.enable_encode = enable_encode
+        self.enable_reverse = enable_reverse
+        self.dim_hidden = dim_hidden
+        self.dim_mlp = 32
+        for name, _ in self.GATES:
+            setattr(self, 'aggr_%s_func' % name, TFMlpAggr(dim_hidden * 2, dim_hidden))
+        for name, _ in self.GATES:
+            setattr(self, 'update_%s_func' % name, nn.GRU(dim_hidden, dim_hidden))
+        self.readout_prob = MLP(dim_hidden, self.dim_mlp, 1, num_layer=3, p_drop=0.2, norm_layer='batchnorm',
+                                act_layer='relu')
+        self.last_confusion = None
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def _sweep_params(self):
+        parts = [getattr(self, 'aggr_%s_func' % n).composed(getattr(self, 'update_%s_func' % n)) for n, _ in self.GATES]
+        return [torch.stack([p[i] for p in parts]) for i in range(5)]
+
+    def forward(self, G):
+        if self.num_rounds != 1:
+            raise NotImplementedError('the HIP sweep implements num_rounds = 1 (the value train.py uses)')
+        plan = plan_of(G, [gid for _, gid in self.GATES])
+        dev = self.hs_linear.weight.device
+        rows = torch.eye(6, dtype=torch.float32, device=dev)          # one_hot(x[:,1], 6) rows
+        enc = getattr(self, self.ENCODER_ATTR)
+        s, t = enc(None, None, G.edge_index, plan=plan, classes=(rows, plan.xcls))
+        hs = ops.linear(s, self.hs_linear.weight, self.hs_linear.bias, x2=t)
+        hf = ops.FuncSweepFn.apply(plan, hs, *self._sweep_params())
+        return hs, hf
+
+    def pred_prob(self, hf, seed=None):
+        return self.readout_prob(hf, clamp01=True, seed=seed)
+
+    def recon_loss(self, hs, pos_edge_index, neg_edge_index=None, want_pred=True):
+        st = ops.linear(hs, self.hs_decompose.weight, self.hs_decompose.bias)
+        if neg_edge_index is None:
+            neg_edge_index = negative_sampling(pos_edge_index, hs.shape[0])
+        loss, counts, pred_bin = ops.ReconLossFn.apply(st, pos_edge_index, neg_edge_index, want_pred)
+        self.last_confusion = counts        # {TP, FP, TN, FN} on device, no host copy needed for metrics
+        Ep, En = pos_edge_index.shape[1], neg_edge_index.shape[1]
+        gt_bin = None
+        if want_pred:
+            gt_bin = torch.zeros(Ep + En, dtype=torch.int32, device=hs.device)
+            gt_bin[:Ep] = 1
+        return loss, pred_bin if want_pred else None, gt_bin
+
+    # ---- checkpoints (dg_ae_model_aig.py:132-160) --------------------------------------------------
+    def load(self, model_path):
+        checkpoint = torch.load(model_path, map_location=lambda storage, loc: storage)
+        src = checkpoint['state_dict']
+        state = {}
+        for k, v in src.items():
+            state[k[7:] if k.startswith('module') and not k.startswith('module_list') else k] = v
+        own = self.state_dict()
+        for k in list(state):
+            if k in own:
+                if state[k].shape != own[k].shape:
+                    print('Skip loading parameter {}, required shape{}, loaded shape{}.'.format(k, own[k].shape, state[k].shape))
+                    state[k] = own[k]
+            else:
+                print('Drop parameter {}.'.format(k))
+        for k in own:
+            if k not in state:
+                print('No param {}.'.format(k))
+                state[k] = own[k]
+        self.load_state_dict(state, strict=False)
+
+    def load_pretrained(self, pretrained_model_path=''):
+        if pretrained_model_path == '':
+            pretrained_model_path = os.path.join(os.path.dirname(__file__), 'pretrained', 'model.pth')
+        self.load(pretrained_model_path)

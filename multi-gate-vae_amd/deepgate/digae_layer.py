@@ -63,11 +63,16 @@ class MultiGCNEncoder(nn.Module):
         return xtab, Wc, bc, gru.weight_hh_l0, gru.bias_hh_l0
 
     def forward(self, x, edge_index, plan=None, classes=None):
-        if x.shape[1] != self.dim_feature:
-            raise ValueError('expected %d node features, got %d' % (self.dim_feature, x.shape[1]))
+        """`classes` = (distinct feature rows [C,F], row id per node uint8 [N]) may stand in for x."""
+        if classes is None:
+            if x.shape[1] != self.dim_feature:
+                raise ValueError('expected %d node features, got %d' % (self.dim_feature, x.shape[1]))
+            classes = feature_classes(x)
+        rows, xcls = classes
+        if rows.shape[1] != self.dim_feature:
+            raise ValueError('expected %d node features, got %d' % (self.dim_feature, rows.shape[1]))
         if plan is None:
-            plan = GraphPlan(edge_index, x.shape[0])
-        rows, xcls = classes if classes is not None else feature_classes(x)
+            plan = GraphPlan(edge_index, xcls.shape[0])
         rows = rows.to(self.update.weight_ih_l0.device)
         f = self._composed(self.aggr, self.update, rows)
         r = self._composed(self.aggr_r, self.update_r, rows)
@@ -83,8 +88,8 @@ class DirectMultiGCNEncoder(nn.Module):
         self.target_conv = MultiGCNEncoder(t_rounds, dim_hidden, dim_feature, enable_reverse, layernorm)
 
     def forward(self, s, t, edge_index, plan=None, classes=None):
-        if plan is None:
-            plan = GraphPlan(edge_index, s.shape[0])
         cs = classes if classes is not None else feature_classes(s)
+        if plan is None:
+            plan = GraphPlan(edge_index, cs[1].shape[0])
         ct = cs if (classes is not None or t is s) else feature_classes(t)
         return self.source_conv(s, edge_index, plan, cs), self.target_conv(t, edge_index, plan, ct)

@@ -106,3 +106,406 @@ class StructEncoderFn(torch.autograd.Function):
         f, r = acc['f'], acc['r']
         return (None, None, None, f['dxtab'], f['dWc'], f['dbc'], f['dWhh'], f['dbhh'],
                 r['dxtab'], r['dWc'], r['dbc'], r['dWhh'], r['dbhh'], dlw, dlb)
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear over node rows (hs_linear / hs_decompose / VAE heads / readout layers)
+# ------------------------------------------------------------------------------------------------
+def _lin_fwd(x1, x2, W, b, M):
+    N, K1 = x1.shape
+    K2 = 0 if x2 is None else x2.shape[1]
+    check(x1, F32, 'x1'); check(x2, F32, 'x2'); check(W, F32, 'W'); check(b, F32, 'b')
+    assert W.shape == (M, K1 + K2)
+    y = torch.empty(N, M, dtype=F32, device=x1.device)
+    _hip.call('mgv_linear_fwd', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
+              ptr(W), ptr(b), M, ptr(y), M)
+    return y
+
+
+def _rowmajor(t):
+    """Tensors whose rows are contiguous (column slices of a wider matrix are fine)."""
+    if t is None:
+        return None
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0:
+        return t
+    return t.contiguous()
+
+
+class LinearFn(torch.autograd.Function):
+    """y = [x1 | x2] W^T + b on the MFMA row-streaming kernel (x2 optional: fuses torch.cat)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, W, b):
+        x1d, x2d = _rowmajor(x1.detach()), _rowmajor(x2.detach()) if x2 is not None else None
+        Wd = W.detach().contiguous()
+        bd = b.detach().contiguous() if b is not None else None
+        ctx.save_for_backward(x1d, x2d, Wd)
+        ctx.has_b = b is not None
+        return _lin_fwd(x1d, x2d, Wd, bd, W.shape[0])
+
+    @staticmethod
+    def backward(ctx, gy):
+        x1, x2, W = ctx.saved_tensors
+        gy = _rowmajor(gy)
+        N, K1 = x1.shape
+        K2 = 0 if x2 is None else x2.shape[1]
+        M = W.shape[0]
+        gx1 = gx2 = gW = gb = None
+        if ctx.needs_input_grad[0]:
+            gx1 = _lin_fwd(gy, None, W[:, :K1].t().contiguous(), None, K1)
+        if x2 is not None and ctx.needs_input_grad[1]:
+            gx2 = _lin_fwd(gy, None, W[:, K1:].t().contiguous(), None, K2)
+        if ctx.needs_input_grad[2] or (ctx.has_b and ctx.needs_input_grad[3]):
+            gW = torch.zeros_like(W)
+            gb = torch.zeros(M, dtype=F32, device=W.device) if ctx.has_b else None
+            _hip.call('mgv_linear_wgrad', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
+                      ptr(gy), gy.stride(0), M, ptr(gW), ptr(gb))
+        return gx1, gx2, gW, gb
+
+
+def linear(x, W, b=None, x2=None):
+    return LinearFn.apply(x, x2, W, b)
+
+
+class GatherSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, plan, reverse):
+        hd = h.detach().contiguous()
+        N, H = hd.shape
+        p, i = plan.csr(reverse)
+        agg = torch.empty_like(hd)
+        deg = torch.empty(N, dtype=F32, device=hd.device)
+        _hip.call('mgv_gather_sum', H, N, ptr(hd), ptr(p), ptr(i), ptr(agg), ptr(deg))
+        ctx.plan, ctx.reverse = plan, reverse
+        ctx.mark_non_differentiable(deg)
+        return agg, deg
+
+    @staticmethod
+    def backward(ctx, gagg, _gdeg):
+        g = gagg.contiguous()
+        N, H = g.shape
+        p, i = ctx.plan.csr(not ctx.reverse)      # the scatter of a gather is the gather over the flipped CSR
+        out = torch.empty_like(g)
+        _hip.call('mgv_gather_sum', H, N, ptr(g), ptr(p), ptr(i), ptr(out), None)
+        return out, None, None
+
+
+def gather_sum(h, nbr_ptr=None, nbr_idx=None, plan=None, reverse=False):
+    if plan is not None:
+        return GatherSumFn.apply(h, plan, reverse)
+    hd = check(h.detach().contiguous(), F32, 'h')
+    N, H = hd.shape
+    agg = torch.empty_like(hd)
+    deg = torch.empty(N, dtype=F32, device=hd.device)
+    _hip.call('mgv_gather_sum', H, N, ptr(hd), ptr(nbr_ptr), ptr(nbr_idx), ptr(agg), ptr(deg))
+    return agg, deg
+
+
+# ------------------------------------------------------------------------------------------------
+# levelised functional sweep
+# ------------------------------------------------------------------------------------------------
+class FuncSweepFn(torch.autograd.Function):
+    """hf = sweep(hs) over levels 1..L-1 (dg_ae_model_aig.py:70-97); parameters are the per-slot
+    composed tensors attn_u [T,2H], Wvc [T,3H,2H], bvc/bih/bhh [T,3H]."""
+
+    @staticmethod
+    def forward(ctx, plan, hs, attn_u, Wvc, bvc, bih, bhh):
+        hsd = check(hs.detach().contiguous(), F32, 'hs')
+        N, H = hsd.shape
+        par = [check(t.detach().contiguous(), F32, 'sweep parameter') for t in (attn_u, Wvc, bvc, bih, bhh)]
+        T = par[0].shape[0]
+        assert plan.has_levels and plan.num_slots == T and plan.N == N
+        hf = torch.zeros(N, H, dtype=F32, device=hsd.device)
+        ltp = (_hip.ctypes.c_int32 * len(plan.level_tile_ptr))(*plan.level_tile_ptr)
+        _hip.call('mgv_func_sweep_fwd', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.tile_start),
+                  ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
+                  *[ptr(t) for t in par])
+        ctx.plan, ctx.par, ctx.ltp = plan, par, ltp
+        ctx.save_for_backward(hsd, hf)
+        return hf
+
+    @staticmethod
+    def backward(ctx, ghf):
+        plan, par = ctx.plan, ctx.par
+        hs, hf = ctx.saved_tensors
+        N, H = hs.shape
+        T = par[0].shape[0]
+        dev = hs.device
+        ghf = check(ghf.contiguous(), F32, 'ghf')
+        ghs = torch.zeros(N, H, dtype=F32, device=dev)
+        dzb = torch.empty(N, 2 * H, dtype=F32, device=dev)
+        alpha = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
+        dsc = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
+        grads = [torch.zeros_like(t) for t in par]
+        WvcT = par[1].transpose(1, 2).contiguous()
+        _hip.call('mgv_func_sweep_bwd', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.tile_start),
+                  ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr),
+                  ptr(plan.out_dst), ptr(plan.out_slot), ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]), ptr(par[1]),
+                  ptr(WvcT), ptr(par[2]), ptr(par[3]), ptr(par[4]), ptr(ghf), ptr(ghs), ptr(dzb), ptr(alpha), ptr(dsc),
+                  *[ptr(g) for g in grads])
+        return (None, ghs, *grads)
+
+
+# ------------------------------------------------------------------------------------------------
+# decoder, reconstruction loss, confusion counters
+# ------------------------------------------------------------------------------------------------
+def _edge_rows(edge_index):
+    ei = edge_index
+    if ei.dtype != torch.int64:
+        ei = ei.long()
+    return ei[0].contiguous(), ei[1].contiguous()
+
+
+class EdgeDotFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s, t, edge_index, sigmoid):
+        sd, td = check(s.detach().contiguous(), F32, 's'), check(t.detach().contiguous(), F32, 't')
+        src, dst = _edge_rows(edge_index)
+        E, H = src.numel(), sd.shape[1]
+        out = torch.empty(E, dtype=F32, device=sd.device)
+        _hip.call('mgv_edge_dot_fwd', H, E, ptr(sd), ptr(td), H, ptr(src), ptr(dst), int(bool(sigmoid)), ptr(out))
+        ctx.save_for_backward(sd, td, src, dst)
+        ctx.sigmoid = bool(sigmoid)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        sd, td, src, dst = ctx.saved_tensors
+        H = sd.shape[1]
+        ds, dt = torch.zeros_like(sd), torch.zeros_like(td)
+        _hip.call('mgv_edge_dot_bwd', H, src.numel(), ptr(sd), ptr(td), H, ptr(src), ptr(dst), int(ctx.sigmoid),
+                  ptr(gout.contiguous()), ptr(ds), ptr(dt))
+        return ds, dt, None, None
+
+
+def edge_dot(s, t, edge_index, sigmoid=True):
+    return EdgeDotFn.apply(s, t, edge_index, sigmoid)
+
+
+def dense_scores(s, t):
+    """s t^T for `forward_all` (tiny graphs only): rows of t act as the weight of a Linear."""
+    M = t.shape[0]
+    if M not in (16, 32, 64, 128):
+        raise NotImplementedError('forward_all is only provided for 16/32/64/128 target rows')
+    return linear(s, t.contiguous(), None)
+
+
+class ReconLossFn(torch.autograd.Function):
+    """-mean log(sigma(<s_u,t_v>)+1e-15) over positives - mean log(1-sigma+1e-15) over negatives
+    (dg_ae_model_aig.py:108-130) on st = hs_decompose(hs) [N,2H]; also the confusion counters and,
+    on request, pred_bin."""
+
+    @staticmethod
+    def forward(ctx, st, pos_edge_index, neg_edge_index, want_pred):
+        std = check(st.detach().contiguous(), F32, 'st')
+        N, H2 = std.shape
+        H = H2 // 2
+        ps, pd = _edge_rows(pos_edge_index)
+        ns, nd = _edge_rows(neg_edge_index)
+        Ep, En = ps.numel(), ns.numel()
+        dev = std.device
+        sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        counts = torch.zeros(4, dtype=torch.int64, device=dev)
+        pred = torch.empty(Ep + En, dtype=torch.int32, device=dev) if want_pred else None
+        t_view = std[:, H:]
+        _hip.call('mgv_recon_loss_fwd', H, ptr(std), ptr(t_view), H2, ptr(ps), ptr(pd), Ep, ptr(ns), ptr(nd), En,
+                  ptr(sums), ptr(counts), ptr(pred))
+        loss = (sums[0] / max(Ep, 1) + sums[1] / max(En, 1)).to(F32)
+        ctx.save_for_backward(std, ps, pd, ns, nd)
+        ctx.mark_non_differentiable(counts)
+        if pred is not None:
+            ctx.mark_non_differentiable(pred)
+            return loss, counts, pred
+        return loss, counts, torch.empty(0, dtype=torch.int32, device=dev)
+
+    @staticmethod
+    def backward(ctx, gloss, _gc, _gp):
+        std, ps, pd, ns, nd = ctx.saved_tensors
+        H2 = std.shape[1]
+        H = H2 // 2
+        dst_ = torch.zeros_like(std)
+        g = gloss.detach().to(F32).reshape(1).contiguous()
+        _hip.call('mgv_recon_loss_bwd', H, ptr(std), ptr(std[:, H:]), H2, ptr(ps), ptr(pd), ps.numel(), ptr(ns), ptr(nd),
+                  ns.numel(), ptr(g), ptr(dst_), ptr(dst_[:, H:]))
+        return dst_, None, None, None
+
+
+def confusion_counts(pred_bin, gt_bin):
+    """{TP, FP, TN, FN} counts (trainer.py:240-244) as an int64[4] device tensor."""
+    counts = torch.zeros(4, dtype=torch.int64, device=pred_bin.device)
+    _hip.call('mgv_confusion', pred_bin.numel(), ptr(check(pred_bin.contiguous(), torch.int32, 'pred_bin')),
+              ptr(check(gt_bin.contiguous(), torch.int32, 'gt_bin')), ptr(counts))
+    return counts
+
+
+# ------------------------------------------------------------------------------------------------
+# losses on node rows
+# ------------------------------------------------------------------------------------------------
+class L1LossFn(torch.autograd.Function):
+    """nn.L1Loss() (mean) as used for the probability task (trainer.py:71,156)."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        xd = check(x.detach().contiguous(), F32, 'x')
+        td = check(target.detach().contiguous(), F32, 'target')
+        assert xd.numel() == td.numel()
+        s = torch.zeros(1, dtype=torch.float64, device=xd.device)
+        _hip.call('mgv_l1_loss_fwd', xd.numel(), ptr(xd), ptr(td), ptr(s))
+        ctx.save_for_backward(xd, td)
+        return (s[0] / max(xd.numel(), 1)).to(F32)
+
+    @staticmethod
+    def backward(ctx, g):
+        xd, td = ctx.saved_tensors
+        dx = torch.empty_like(xd)
+        gs = g.detach().to(F32).reshape(1).contiguous()
+        _hip.call('mgv_l1_loss_bwd', xd.numel(), ptr(xd), ptr(td), ptr(gs), ptr(dx))
+        return dx, None
+
+
+def l1_loss(x, target):
+    return L1LossFn.apply(x, target)
+
+
+class FuncLossFn(torch.autograd.Function):
+    """L1(z(1 - cos(hf[a], hf[b])), z(tt_sim)) with z = zero_normalization (trainer.py:158-163)."""
+
+    @staticmethod
+    def forward(ctx, hf, tt_pair_index, tt_sim):
+        hfd = check(hf.detach().contiguous(), F32, 'hf')
+        pa, pb = _edge_rows(tt_pair_index)
+        tt = check(tt_sim.detach().to(F32).contiguous(), F32, 'tt_sim')
+        P, H = pa.numel(), hfd.shape[1]
+        dis = torch.empty(P, dtype=F32, device=hfd.device)
+        ws = torch.zeros(8, dtype=torch.float64, device=hfd.device)
+        _hip.call('mgv_func_loss_fwd', H, P, ptr(hfd), ptr(pa), ptr(pb), ptr(tt), 1e-8, ptr(dis), ptr(ws))
+        ctx.save_for_backward(hfd, pa, pb, tt, dis, ws)
+        return (ws[4] / P).to(F32)
+
+    @staticmethod
+    def backward(ctx, g):
+        hfd, pa, pb, tt, dis, ws = ctx.saved_tensors
+        dhf = torch.zeros_like(hfd)
+        gs = g.detach().to(F32).reshape(1).contiguous()
+        _hip.call('mgv_func_loss_bwd', hfd.shape[1], pa.numel(), ptr(hfd), ptr(pa), ptr(pb), ptr(tt), ptr(dis), 1e-8,
+                  ptr(ws), ptr(gs), ptr(dhf))
+        return dhf, None, None
+
+
+def func_loss(hf, tt_pair_index, tt_sim):
+    return FuncLossFn.apply(hf, tt_pair_index, tt_sim)
+
+
+# ------------------------------------------------------------------------------------------------
+# readout: BatchNorm1d + ReLU + Dropout block, 32 -> 1 head with clamp
+# ------------------------------------------------------------------------------------------------
+class BnReluDropFn(torch.autograd.Function):
+    """dropout_p(relu(batch_norm(y))) for y [N,C] (mlp.py:31-36).  training=True uses batch statistics
+    and updates the running buffers in place like nn.BatchNorm1d (momentum 0.1, unbiased running var)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, p_drop, seed, momentum, eps):
+        yd = check(y.detach().contiguous(), F32, 'y')
+        N, C = yd.shape
+        dev = yd.device
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        if training:
+            sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+            _hip.call('mgv_colstats', N, C, ptr(yd), C, ptr(sums))
+            mean64 = sums[:C] / N
+            var64 = (sums[C:] / N - mean64 * mean64).clamp_min(0.0)
+            mean, var = mean64.to(F32), var64.to(F32)
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(momentum * mean)
+                running_var.mul_(1 - momentum).add_(momentum * (var64 * (N / max(N - 1, 1))).to(F32))
+        else:
+            mean, var = running_mean.detach().clone(), running_var.detach().clone()
+        invstd = torch.rsqrt(var + eps).contiguous()
+        mean = mean.contiguous()
+        p = float(p_drop) if training else 0.0
+        a = torch.empty_like(yd)
+        _hip.call('mgv_bn_act_fwd', N, C, ptr(yd), ptr(mean), ptr(invstd), ptr(g), ptr(b), p, int(seed), ptr(a))
+        ctx.save_for_backward(yd, mean, invstd, g, b)
+        ctx.cfg = (bool(training), p, int(seed))
+        return a
+
+    @staticmethod
+    def backward(ctx, ga):
+        yd, mean, invstd, g, b = ctx.saved_tensors
+        training, p, seed = ctx.cfg
+        N, C = yd.shape
+        ga = check(ga.contiguous(), F32, 'ga')
+        dz = torch.empty_like(yd)
+        sums = torch.zeros(2 * C, dtype=torch.float64, device=yd.device)
+        _hip.call('mgv_bn_act_bwd', N, C, ptr(yd), ptr(mean), ptr(invstd), ptr(g), ptr(b), p, seed, ptr(ga), ptr(dz), ptr(sums))
+        dy = torch.empty_like(yd)
+        _hip.call('mgv_bn_bwd_apply', N, C, ptr(yd), ptr(mean), ptr(invstd), ptr(g), ptr(dz), ptr(sums), int(training), ptr(dy))
+        return dy, sums[C:].to(F32), sums[:C].to(F32), None, None, None, None, None, None, None
+
+
+class HeadFn(torch.autograd.Function):
+    """clamp(a w^T + b, 0, 1): last Linear of the readout MLP + torch.clamp (dg_ae_model_aig.py:105)."""
+
+    @staticmethod
+    def forward(ctx, a, w, b, clamp01):
+        ad = check(a.detach().contiguous(), F32, 'a')
+        wd, bd = w.detach().contiguous().reshape(-1), b.detach().contiguous().reshape(-1)
+        N, C = ad.shape
+        prob = torch.empty(N, 1, dtype=F32, device=ad.device)
+        _hip.call('mgv_readout_head_fwd', N, C, ptr(ad), ptr(wd), ptr(bd), int(bool(clamp01)), ptr(prob))
+        ctx.save_for_backward(ad, wd, bd)
+        ctx.wshape, ctx.clamp01 = w.shape, int(bool(clamp01))
+        return prob
+
+    @staticmethod
+    def backward(ctx, gprob):
+        ad, wd, bd = ctx.saved_tensors
+        N, C = ad.shape
+        gp = check(gprob.contiguous().reshape(-1), F32, 'gprob')
+        da = torch.empty_like(ad)
+        dw = torch.zeros_like(wd)
+        db = torch.zeros_like(bd)
+        _hip.call('mgv_readout_head_bwd', N, C, ptr(ad), ptr(wd), ptr(bd), ctx.clamp01, ptr(gp), ptr(da), ptr(dw), ptr(db))
+        return da, dw.reshape(ctx.wshape), db, None
+
+
+# ------------------------------------------------------------------------------------------------
+# VAE sampler + KL
+# ------------------------------------------------------------------------------------------------
+class ReparamFn(torch.autograd.Function):
+    """z = mu + exp(logstd) * eps and klsum = sum(1 + 2 logstd - mu^2 - exp(logstd)^2)
+    (digvae_model.py:138-141, trainer.py:146-147)."""
+
+    @staticmethod
+    def forward(ctx, mu, logstd, eps, seed):
+        mud, lsd = check(mu.detach().contiguous(), F32, 'mu'), check(logstd.detach().contiguous(), F32, 'logstd')
+        n = mud.numel()
+        z = torch.empty_like(mud)
+        kl = torch.zeros(1, dtype=torch.float64, device=mud.device)
+        if eps is None:
+            eps_used = torch.empty_like(mud)
+            _hip.call('mgv_reparam_fwd', n, ptr(mud), ptr(lsd), None, int(seed), ptr(eps_used), ptr(z), ptr(kl))
+        else:
+            eps_used = check(eps.detach().contiguous(), F32, 'eps')
+            _hip.call('mgv_reparam_fwd', n, ptr(mud), ptr(lsd), ptr(eps_used), 0, None, ptr(z), ptr(kl))
+        ctx.save_for_backward(mud, lsd, eps_used)
+        return z, kl[0].to(F32)
+
+    @staticmethod
+    def backward(ctx, gz, gkl):
+        mud, lsd, eps = ctx.saved_tensors
+        dmu, dls = torch.empty_like(mud), torch.empty_like(mud)
+        gzc = gz.contiguous() if gz is not None else None
+        gk = gkl.detach().to(F32).reshape(1).contiguous() if gkl is not None else None
+        _hip.call('mgv_reparam_bwd', mud.numel(), ptr(mud), ptr(lsd), ptr(eps), ptr(gzc), ptr(gk), 1.0, ptr(dmu), ptr(dls))
+        return dmu, dls, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------------------
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, betas, eps, weight_decay, grad_scale, step):
+    for n, t in (('param', param), ('grad', grad), ('exp_avg', exp_avg), ('exp_avg_sq', exp_avg_sq)):
+        check(t, F32, n)
+    _hip.call('mgv_adam_step', param.numel(), ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), float(lr),
+              float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(grad_scale), int(step))

@@ -1,0 +1,219 @@
+"""Trainer with the reference's surface (DG_VAE/deepgate/trainer.py:20-277): same constructor
+arguments, `set_training_args`, `run_batch` -> {'recon_loss','pred_bin','gt_bin','prob_loss','func_loss'},
+`train`, `save`, `load`, `resume`, same checkpoint dict.  Differences, all deliberate (SURVEY.md
+Appendix B): gradients ARE averaged across ranks (one RCCL all-reduce of the flat gradient buffer per
+step), only rank 0 writes checkpoints, step metrics come from four device-side counters instead of a
+host copy of every edge prediction, and the dead N x N negative mask of the edge split is never built.
+"""
+import os
+import time
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import ops
+from .data import CircuitBatch
+from .optim import FlatAdam
+from .synthetic import collate as collate_arrays
+from .utils.logger import Logger
+from .utils.model_utils import load_model
+from .utils.utils import AverageMeter
+
+
+class GraphLoader:
+    """Minimal stand-in for torch_geometric's DataLoader over a list of per-graph array dicts:
+    drop_last batching, optional shuffling, DistributedSampler-style rank striding
+    (trainer.py:178-195)."""
+
+    def __init__(self, graphs, batch_size, shuffle, rank=0, world_size=1, seed=0):
+        self.graphs, self.batch_size, self.shuffle = graphs, batch_size, shuffle
+        self.rank, self.world_size, self.seed, self.epoch = rank, world_size, seed, 0
+
+    def _indices(self):
+        n = len(self.graphs)
+        if self.shuffle or self.world_size > 1:
+            g = torch.Generator().manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(n, generator=g).tolist() if self.shuffle else list(range(n))
+        else:
+            idx = list(range(n))
+        if self.world_size > 1:
+            total = (n + self.world_size - 1) // self.world_size * self.world_size
+            idx = (idx + idx[:total - n])[self.rank:total:self.world_size]
+        return idx
+
+    def __len__(self):
+        return len(self._indices()) // self.batch_size
+
+    def __iter__(self):
+        idx = self._indices()
+        self.epoch += 1
+        for b in range(len(idx) // self.batch_size):
+            chunk = [self.graphs[i] for i in idx[b * self.batch_size:(b + 1) * self.batch_size]]
+            yield CircuitBatch.from_arrays(collate_arrays(chunk))
+
+
+class Trainer():
+    def __init__(self, args, model, training_id='default', save_dir='./exp', lr=1e-4,
+                 rc_prob_func_weight=[1.0, 4.0, 2.0], emb_dim=128, device='cpu', batch_size=32, num_workers=0,
+                 distributed=True):
+        super(Trainer, self).__init__()
+        self.args = args
+        self.emb_dim = emb_dim
+        self.device = device
+        self.lr = lr
+        self.lr_step = -1
+        self.rc_prob_func_weight = list(rc_prob_func_weight)
+        os.makedirs(save_dir, exist_ok=True)
+        self.log_dir = os.path.join(save_dir, training_id)
+        os.makedirs(self.log_dir, exist_ok=True)
+        time_str = time.strftime('%Y-%m-%d-%H-%M')
+        self.log_path = os.path.join(self.log_dir, 'log-{}.txt'.format(time_str))
+        self.batch_size = batch_size
+        self.num_workers = num_workers
+        self.distributed = distributed
+        self.local_rank, self.rank, self.world_size = 0, 0, 1
+        if self.distributed:
+            if 'LOCAL_RANK' in os.environ:
+                self.local_rank = int(os.environ['LOCAL_RANK'])
+            self.device = 'cuda:%d' % self.local_rank
+            torch.cuda.set_device(self.local_rank)
+            if not torch.distributed.is_initialized():
+                # backend 'nccl' is RCCL on ROCm; rendezvous from the torchrun environment
+                torch.distributed.init_process_group(backend='nccl', init_method='env://')
+            self.world_size = torch.distributed.get_world_size()
+            self.rank = torch.distributed.get_rank()
+            print('Training in distributed mode. Device {}, Process {:}, total {:}.'.format(self.device, self.rank, self.world_size))
+        else:
+            print('Training in single device: ', self.device)
+        self.reg_loss = ops.l1_loss                     # nn.L1Loss() of the reference, on the HIP kernel
+        self.model = model.to(self.device)
+        self.optimizer = FlatAdam(self.model.parameters(), lr=self.lr)
+        if self.world_size > 1:
+            for p in self.model.parameters():           # every rank starts from rank 0's weights
+                torch.distributed.broadcast(p.data, 0)
+            for b in self.model.buffers():
+                torch.distributed.broadcast(b.data, 0)
+        self.model_epoch = 0
+        if self.local_rank == 0:
+            self.logger = Logger(self.log_path)
+
+    def set_training_args(self, rc_prob_func_weight=[], lr=-1, lr_step=-1, device='null'):
+        if len(rc_prob_func_weight) == 3 and list(rc_prob_func_weight) != self.rc_prob_func_weight:
+            print('[INFO] Update rc_prob_func_weight from {} to {}'.format(self.rc_prob_func_weight, rc_prob_func_weight))
+            self.rc_prob_func_weight = list(rc_prob_func_weight)
+        if lr > 0 and lr != self.lr:
+            print('[INFO] Update learning rate from {} to {}'.format(self.lr, lr))
+            self.lr = lr
+            for param_group in self.optimizer.param_groups:
+                param_group['lr'] = self.lr
+        if lr_step > 0 and lr_step != self.lr_step:
+            print('[INFO] Update learning rate step from {} to {}'.format(self.lr_step, lr_step))
+            self.lr_step = lr_step
+        if device != 'null' and device != self.device:
+            print('[INFO] Update device from {} to {}'.format(self.device, device))
+            self.device = device
+            self.model = self.model.to(self.device)
+
+    def save(self, path):
+        torch.save({'epoch': self.model_epoch, 'state_dict': self.model.state_dict(),
+                    'optimizer': self.optimizer.state_dict()}, path)
+
+    def load(self, path):
+        checkpoint = torch.load(path, map_location='cpu')
+        self.optimizer.load_state_dict(checkpoint['optimizer'])
+        for param_group in self.optimizer.param_groups:
+            self.lr = param_group['lr']
+        self.model_epoch = checkpoint['epoch']
+        self.model.load(path)
+        print('[INFO] Continue training from epoch {:}'.format(self.model_epoch))
+        return path
+
+    def resume(self):
+        model_path = os.path.join(self.log_dir, 'model_last.pth')
+        if os.path.exists(model_path):
+            self.model, self.optimizer, self.model_epoch = load_model(self.model, model_path, optimizer=self.optimizer,
+                                                                      local_rank=self.local_rank, device=self.device)
+            return True
+        return False
+
+    def run_batch(self, batch, want_pred=True):
+        """Forward + the three losses (trainer.py:131-174).  `general_train_test_split_edges` with zero
+        val/test ratios only permutes the edges (preprocessing.py:41-50), to which the mean over edges is
+        invariant: train_pos_edge_index is the batch's edge_index."""
+        batch.train_pos_edge_index = batch.edge_index
+        hs, hf = self.model(batch)
+        neg = getattr(batch, 'neg_edge_index', None)
+        loss, pred_bin, gt_bin = self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred)
+        loss_status = {'recon_loss': loss, 'pred_bin': pred_bin, 'gt_bin': gt_bin}
+        if 'VAE' in getattr(self.args, 'model', '') and hasattr(self.model, 'kl_loss'):
+            s_kl, t_kl = self.model.kl_loss()
+            loss_status['kl_loss'] = s_kl + t_kl          # computed, not added (as in the reference)
+        prob = self.model.pred_prob(hf)
+        loss_status['prob_loss'] = self.reg_loss(prob, batch['prob'])
+        loss_status['func_loss'] = ops.func_loss(hf, batch['tt_pair_index'], batch['tt_sim'])
+        loss_status['confusion'] = self.model.last_confusion
+        return loss_status
+
+    def weighted_loss(self, loss_status):
+        w = self.rc_prob_func_weight
+        return w[0] * loss_status['recon_loss'] + w[1] * loss_status['prob_loss'] + w[2] * loss_status['func_loss']
+
+    def train_step(self, batch, want_pred=False):
+        """zero_grad -> run_batch -> weighted loss -> backward -> (all-reduce) Adam (trainer.py:222-234)."""
+        self.optimizer.zero_grad()
+        loss_status = self.run_batch(batch, want_pred=want_pred)
+        loss = self.weighted_loss(loss_status)
+        loss.backward()
+        self.optimizer.step()
+        return loss_status
+
+    def _loader(self, dataset, shuffle):
+        if isinstance(dataset, GraphLoader):
+            return dataset
+        return GraphLoader(dataset, self.batch_size, shuffle, self.rank, self.world_size)
+
+    def train(self, num_epoch, train_dataset, val_dataset):
+        train_loader = self._loader(train_dataset, shuffle=not self.distributed)
+        val_loader = self._loader(val_dataset, shuffle=not self.distributed)
+        batch_time = AverageMeter()
+        stats = {k: AverageMeter() for k in ('recon', 'prob', 'func', 'acc', 'tp', 'fp', 'tn', 'fn')}
+        print('[INFO] Start training, lr = {:.4f}'.format(self.optimizer.param_groups[0]['lr']))
+        for epoch in range(num_epoch):
+            for phase in ['train', 'val']:
+                loader = train_loader if phase == 'train' else val_loader
+                self.model.train() if phase == 'train' else self.model.eval()
+                for iter_id, batch in enumerate(loader):
+                    batch = batch.to(self.device)
+                    time_stamp = time.time()
+                    if phase == 'train':
+                        loss_status = self.train_step(batch)
+                    else:
+                        with torch.no_grad():
+                            loss_status = self.run_batch(batch, want_pred=False)
+                    # one small device->host copy per step: 3 losses + 4 counters
+                    vals = torch.cat([torch.stack([loss_status['recon_loss'].detach(), loss_status['prob_loss'].detach(),
+                                                   loss_status['func_loss'].detach()]).double(),
+                                      loss_status['confusion'].double()]).tolist()
+                    tot = max(sum(vals[3:]), 1.0)
+                    tp, fp, tn, fn = (v / tot for v in vals[3:])
+                    batch_time.update(time.time() - time_stamp)
+                    for k, v in zip(('recon', 'prob', 'func', 'acc', 'tp', 'fp', 'tn', 'fn'),
+                                    (vals[0], vals[1], vals[2], tp + tn, tp, fp, tn, fn)):
+                        stats[k].update(v)
+                if phase == 'train' and self.model_epoch % 10 == 0 and self.rank == 0:
+                    self.save(os.path.join(self.log_dir, 'model_{:}.pth'.format(self.model_epoch)))
+                    self.save(os.path.join(self.log_dir, 'model_last.pth'))
+                if self.local_rank == 0:
+                    line = '{}| Epoch: {:}/{:} |Recon: {:.4f} |ACC: {:.2f} |Prob: {:.4f} |Func: {:.4f}|Net: {:.2f}s\n'.format(
+                        phase, epoch, num_epoch, stats['recon'].avg, stats['acc'].avg * 100, stats['prob'].avg,
+                        stats['func'].avg, batch_time.avg)
+                    self.logger.write(line)
+                    print(line, end='')
+            self.model_epoch += 1
+            if self.lr_step > 0 and self.model_epoch % self.lr_step == 0:
+                self.lr *= 0.1
+                if self.local_rank == 0:
+                    print('[INFO] Learning rate decay to {}'.format(self.lr))
+                for param_group in self.optimizer.param_groups:
+                    param_group['lr'] = self.lr

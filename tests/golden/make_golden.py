@@ -235,6 +235,20 @@ def g3_ops():
     for k, p in gru.named_parameters():
         out['lvl_grad_gru_' + k] = p.grad.numpy().copy()
 
+    # -- the same level with h0 = 0 (num_rounds = 1: a node is updated once, from a zero state)
+    aggr.zero_grad(); gru.zero_grad()
+    ns0 = node_state.detach().clone().requires_grad_(True)
+    m0 = aggr(ns0, sub_ei, None)
+    lm0 = torch.index_select(m0, 0, l_node)
+    _, hnew0 = gru(lm0.unsqueeze(0), torch.zeros(1, len(targets), H))
+    hnew0 = hnew0.squeeze(0)
+    (hnew0 * upl).sum().backward()
+    out.update(lvl0_hnew=hnew0.detach().numpy(), lvl0_grad_node_state=ns0.grad.numpy())
+    for k, p in aggr.named_parameters():
+        out['lvl0_grad_aggr_' + k] = p.grad.numpy().copy()
+    for k, p in gru.named_parameters():
+        out['lvl0_grad_gru_' + k] = p.grad.numpy().copy()
+
     # -- readout MLP with BatchNorm batch statistics (dropout p forced to 0), clamp, L1
     torch.manual_seed(23)
     mlp = MLP(H, 32, 1, num_layer=3, p_drop=0.2, norm_layer='batchnorm', act_layer='relu')
