@@ -89,10 +89,35 @@ def stream():
 _ERR = {-1: 'MGV_EINVAL (bad argument)', -2: 'MGV_EUNSUPPORTED (unsupported size)'}
 
 
+_profile = None      # {launcher name: [(start event, end event), ...]} while profiling is on
+
+
+def profile(enable):
+    """Bracket every launcher call with a pair of HIP events on the stream it is enqueued on
+    (bench.py reads per-launcher device time from them).  Returns the previous table."""
+    global _profile
+    old = _profile
+    _profile = {} if enable else None
+    return old
+
+
+def profile_summary(table):
+    """{name: (calls, total ms)}; synchronises."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(s.elapsed_time(e) for s, e in v)) for k, v in (table or {}).items()}
+
+
 def call(name, *args):
     """Call launcher `name`; the current torch stream is appended as the last argument."""
     lib = load()
-    rc = getattr(lib, name)(*args, stream())
+    if _profile is not None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = getattr(lib, name)(*args, stream())
+        e.record()
+        _profile.setdefault(name, []).append((s, e))
+    else:
+        rc = getattr(lib, name)(*args, stream())
     if rc != 0:
         raise HipLibraryError('%s failed: %s' % (name, _ERR.get(rc, 'hipError_t %d' % rc)))
 

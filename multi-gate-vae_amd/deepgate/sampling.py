@@ -8,12 +8,18 @@ HIP recon-loss kernel; SURVEY.md §8f row 3 lists a fused sampler as follow-up w
 import torch
 
 
-def negative_sampling(pos_edge_index, num_nodes, num_neg_samples=None, generator=None):
-    dev = pos_edge_index.device
+def sorted_edge_keys(pos_edge_index, num_nodes):
+    """Sorted src*N+dst keys of the non-self-loop edges (static per batch: cache them)."""
     src, dst = pos_edge_index[0].long(), pos_edge_index[1].long()
-    N = int(num_nodes)
     keep = src != dst
-    keys = torch.sort(src[keep] * N + dst[keep]).values
+    return torch.sort(src[keep] * int(num_nodes) + dst[keep]).values
+
+
+def negative_sampling(pos_edge_index, num_nodes, num_neg_samples=None, generator=None, keys=None):
+    dev = pos_edge_index.device
+    N = int(num_nodes)
+    if keys is None:
+        keys = sorted_edge_keys(pos_edge_index, N)
     want = int(keys.numel()) + N if num_neg_samples is None else int(num_neg_samples)
     out = torch.empty((2, 0), dtype=torch.long, device=dev)
     guard = 0

@@ -15,6 +15,7 @@ from torch import nn
 from . import ops
 from .data import CircuitBatch
 from .optim import FlatAdam
+from .sampling import sorted_edge_keys
 from .synthetic import collate as collate_arrays
 from .utils.logger import Logger
 from .utils.model_utils import load_model
@@ -144,7 +145,12 @@ class Trainer():
         batch.train_pos_edge_index = batch.edge_index
         hs, hf = self.model(batch)
         neg = getattr(batch, 'neg_edge_index', None)
-        loss, pred_bin, gt_bin = self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred)
+        keys = None
+        if neg is None:                      # sorted edge keys for the rejection sampler: static per batch
+            keys = getattr(batch, '_mgv_edge_keys', None)
+            if keys is None:
+                keys = batch._mgv_edge_keys = sorted_edge_keys(batch.edge_index, batch.num_nodes)
+        loss, pred_bin, gt_bin = self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred, edge_keys=keys)
         loss_status = {'recon_loss': loss, 'pred_bin': pred_bin, 'gt_bin': gt_bin}
         if 'VAE' in getattr(self.args, 'model', '') and hasattr(self.model, 'kl_loss'):
             s_kl, t_kl = self.model.kl_loss()

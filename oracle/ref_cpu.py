@@ -140,7 +140,7 @@ class LevelPlan:
                 self.groups.append((level, gname, nodes, self.src[eidx], seg))
 
 
-def model_forward(p, ctype, batch, s_rounds=4, t_rounds=4, layernorm=True, num_rounds=1, plan=None):
+def model_forward(p, ctype, batch, s_rounds=4, t_rounds=4, layernorm=True, num_rounds=1, plan=None, fast=False):
     """Model.forward (dg_ae_model_aig.py:52-100 and siblings) -> (hs, hf, s, t)."""
     x = batch['x']
     N = x.shape[0]
@@ -151,6 +151,9 @@ def model_forward(p, ctype, batch, s_rounds=4, t_rounds=4, layernorm=True, num_r
     hf = torch.zeros(N, H)
     if plan is None:
         plan = LevelPlan(ctype, batch['edge_index'], batch['gate'], batch['forward_level'])
+    if fast:
+        assert num_rounds == 1
+        return hs, sweep_fast(p, ctype, hs, plan), s, t
     for _ in range(num_rounds):
         level_writes = []
         cur = None
@@ -170,6 +173,64 @@ def model_forward(p, ctype, batch, s_rounds=4, t_rounds=4, layernorm=True, num_r
         for nd, val in level_writes:
             hf = hf.index_put((nd,), val)
     return hs, hf, s, t
+
+
+def _group_update(p, gname, xs_s, xs_f, xd_s, xd_f, seg, n_seg):
+    """TFMlpAggr + GRU of one (level, gate) group from a zero state (num_rounds = 1)."""
+    msg = tf_mlp_aggr(p, 'aggr_%s_func' % gname, torch.cat([xs_s, xs_f], dim=-1), torch.cat([xd_s, xd_f], dim=-1), seg, n_seg)
+    return gru_cell(p, 'update_%s_func' % gname, msg, msg.new_zeros((n_seg, msg.shape[1])))
+
+
+class _SweepFast(torch.autograd.Function):
+    """The level loop of `model_forward` with O(edges) cost.  The plain autograd version pays O(N) per
+    (level, gate) group — `index_put` copies and dense index_select gradients, the same O(L*N) the
+    reference pays with its per-level `torch.cat([hs, hf])` — which makes whole-workload CPU timing
+    meaningless.  Here every group is still differentiated by torch autograd (locally, on the rows it
+    touches); only the order of the groups and the accumulation into dhs/dhf are written out.
+    `tests/test_oracle_golden.py` checks it against the plain version.  num_rounds = 1 only."""
+
+    @staticmethod
+    def forward(ctx, hs, plan, names, *params):
+        p = dict(zip(names, params))
+        hf = torch.zeros_like(hs)
+        with torch.no_grad():
+            for level, gname, nodes, esrc, seg in plan.groups:
+                dn = nodes.index_select(0, seg)
+                hf[nodes] = _group_update(p, gname, hs[esrc], hf[esrc], hs[dn], hf[dn], seg, nodes.numel())
+        ctx.plan, ctx.names = plan, names
+        ctx.save_for_backward(hs, hf, *params)
+        return hf
+
+    @staticmethod
+    def backward(ctx, ghf):
+        hs, hf, *params = ctx.saved_tensors
+        names = ctx.names
+        ghf = ghf.clone()
+        ghs = torch.zeros_like(hs)
+        gpar = [torch.zeros_like(t) for t in params]
+        for level, gname, nodes, esrc, seg in reversed(ctx.plan.groups):
+            dn = nodes.index_select(0, seg)
+            leaves = [hs[esrc], hf[esrc], hs[dn], hf[dn]]
+            used = [i for i, n in enumerate(names) if ('_%s_func' % gname) in n]
+            local = [t.detach().requires_grad_(True) for t in leaves] + [params[i].detach().requires_grad_(True) for i in used]
+            with torch.enable_grad():
+                pl = {names[i]: local[4 + k] for k, i in enumerate(used)}
+                out = _group_update(pl, gname, local[0], local[1], local[2], local[3], seg, nodes.numel())
+            gs = torch.autograd.grad(out, local, grad_outputs=ghf[nodes], allow_unused=True)
+            ghs.index_add_(0, esrc, gs[0]); ghf.index_add_(0, esrc, gs[1])
+            if gs[2] is not None:
+                ghs.index_add_(0, dn, gs[2])
+            if gs[3] is not None:
+                ghf.index_add_(0, dn, gs[3])
+            for k, i in enumerate(used):
+                if gs[4 + k] is not None:
+                    gpar[i] += gs[4 + k]
+        return (ghs, None, None, *gpar)
+
+
+def sweep_fast(p, ctype, hs, plan):
+    names = [k for k in p if k.startswith('aggr_') or k.startswith('update_')]
+    return _SweepFast.apply(hs, plan, names, *[p[k] for k in names])
 
 
 def readout_prob(p, hf, training, bn_state=None, p_drop=0.0, momentum=0.1):
@@ -222,11 +283,11 @@ def func_loss(hf, tt_pair_index, tt_sim):
 
 
 def run_batch(p, ctype, batch, training=True, bn_state=None, p_drop=0.0, s_rounds=4, t_rounds=4,
-              layernorm=True, num_rounds=1, plan=None):
+              layernorm=True, num_rounds=1, plan=None, fast=False):
     """Trainer.run_batch (trainer.py:131-174).  The edge split keeps only its live effect — a
     permutation of the edges, to which the mean over edges is invariant — and never builds the dead
     N x N mask (preprocessing.py:56-69)."""
-    hs, hf, s, t = model_forward(p, ctype, batch, s_rounds, t_rounds, layernorm, num_rounds, plan)
+    hs, hf, s, t = model_forward(p, ctype, batch, s_rounds, t_rounds, layernorm, num_rounds, plan, fast)
     rl, pred_bin, gt_bin = recon_loss(p, hs, batch['edge_index'], batch['neg_edge_index'])
     prob = readout_prob(p, hf, training, bn_state, p_drop)
     pl = F.l1_loss(prob, batch['prob'])

@@ -206,3 +206,24 @@ def test_cfg1_trajectory_loose():
         opt.step()
         got = [float(ls['recon_loss']), float(ls['prob_loss']), float(ls['func_loss'])]
         np.testing.assert_allclose(got, z['losses'][step], rtol=2e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize('name', ['g1_xmg', 'g2_aig'])
+def test_fast_sweep_equals_plain_autograd_sweep(name):
+    """The O(edges) level loop used for whole-workload CPU timing is the same function."""
+    z = load(name)
+    ctype, Rr, p, batch = _model_case(z)
+    p2 = R.params_from_npz(z)
+    outs = []
+    for params, fast in ((p, False), (p2, True)):
+        bn = {k: v.clone() for k, v in params.items() if 'running_' in k}
+        ls = R.run_batch(params, ctype, batch, training=True, bn_state=bn, p_drop=0.0, s_rounds=Rr, t_rounds=Rr, fast=fast)
+        R.weighted_loss(ls, z['meta_weights']).backward()
+        outs.append(ls)
+    close(outs[1]['hf'], outs[0]['hf'].detach().numpy(), 1e-6, 1e-6)
+    for k in p:
+        if p[k].requires_grad:
+            ga = p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])
+            gb = p2[k].grad if p2[k].grad is not None else torch.zeros_like(p2[k])
+            scale = max(1e-6, float(ga.abs().max()))
+            np.testing.assert_allclose(gb.numpy(), ga.numpy(), rtol=1e-4, atol=1e-5 * scale + 1e-7, err_msg=k)
