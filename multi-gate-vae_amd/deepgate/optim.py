@@ -75,16 +75,22 @@ class FlatAdam(torch.optim.Optimizer):
             super().zero_grad(set_to_none=False)
 
     @torch.no_grad()
-    def step(self, closure=None):
-        loss = closure() if closure is not None else None
+    def reduce_gradients(self):
+        """One all-reduce (sum) of the flat gradient buffer over the default process group (RCCL on the
+        GPUs, gloo in the CPU tests); returns the factor that turns the sum into the mean."""
         if not self._is_flat():
             self._flatten()
+        if self.sync_grads and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self._flat['grad'], op=dist.ReduceOp.SUM)
+            return 1.0 / dist.get_world_size()
+        return 1.0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        scale = self.reduce_gradients()
         f = self._flat
         g = self.param_groups[0]
-        scale = 1.0
-        if self.sync_grads and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(f['grad'], op=dist.ReduceOp.SUM)
-            scale = 1.0 / dist.get_world_size()
         self._step += 1
         ops.adam_step(f['param'], f['grad'], f['m'], f['v'], g['lr'], g['betas'], g['eps'], g['weight_decay'], scale, self._step)
         return loss

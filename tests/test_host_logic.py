@@ -1,0 +1,185 @@
+"""CPU tests of the host-side logic: graph plan vs brute force, synthetic generator, loader sharding,
+C-ABI header/library agreement, flat optimiser bookkeeping, and the world_size-2 gradient exchange
+over gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+import deepgate
+from deepgate import synthetic as syn
+from deepgate.graph_plan import GraphPlan
+
+
+def test_header_and_library_agree():
+    """Every `int mgv_*` declared in include/mgvae_hip.h is exported by the built library (no compute)."""
+    from deepgate import _hip
+    sigs = _hip.parse_header()
+    assert len(sigs) >= 26
+    if not os.path.exists(_hip.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    for name in sigs:
+        assert hasattr(lib, name), name
+    out = subprocess.run(['nm', '-D', '--defined-only', _hip.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r'\bT (mgv_\w+)', out))
+    assert exported == set(sigs), exported ^ set(sigs)
+    assert lib.mgv_abi_version() >= 1
+
+
+def test_missing_gpu_fails_loudly():
+    """No CPU fallback: a CPU tensor is refused before anything is launched."""
+    from deepgate import _hip, ops
+    with pytest.raises(_hip.HipLibraryError):
+        ops.l1_loss(torch.zeros(4), torch.zeros(4))
+
+
+def test_synthetic_generator_matches_survey_counts_and_is_deterministic():
+    a = syn.make_batch(1)
+    b = syn.make_batch(1)
+    assert a['num_nodes'] == 4096 and a['edge_index'].shape == (2, 6480)
+    for k in ('edge_index', 'prob', 'tt_sim', 'neg_edge_index'):
+        assert np.array_equal(a[k], b[k])
+    g = syn.make_graph('xmg', 96, 6, 5, n_inputs=12)
+    ei, lv = g['edge_index'], g['forward_level']
+    asap = np.zeros(96, dtype=np.int64)
+    np.maximum.at(asap, ei[1], lv[ei[0]] + 1)          # valid because ids are level-sorted
+    assert np.array_equal(asap, lv)
+    key = ei[0] * 96 + ei[1]
+    assert len(np.unique(key)) == len(key)            # distinct fan-ins
+    nkey = g['neg_edge_index'][0] * 96 + g['neg_edge_index'][1]
+    assert not np.isin(nkey, key).any() and (g['neg_edge_index'][0] != g['neg_edge_index'][1]).all()
+    fan = np.bincount(ei[1], minlength=96)
+    gate = g['gate'].reshape(-1).astype(int)
+    want = {0: 0, 1: 3, 2: 1, 3: 2, 4: 2, 5: 2}
+    assert all(fan[i] == want[gate[i]] for i in range(96))
+
+
+def test_graph_plan_against_brute_force():
+    g = syn.collate([syn.make_graph('xmg', 96, 6, 5, n_inputs=12), syn.make_graph('xmg', 80, 4, 6, n_inputs=8)])
+    ei = torch.from_numpy(g['edge_index'])
+    N = g['num_nodes']
+    plan = GraphPlan(ei, N).set_levels(torch.from_numpy(g['gate']), torch.from_numpy(g['forward_level']), [3, 2, 5, 1, 4])
+    src, dst = g['edge_index']
+    for v in range(N):
+        ins = sorted(src[dst == v].tolist())
+        got = plan.in_src[plan.in_ptr[v]:plan.in_ptr[v + 1]].tolist()
+        assert sorted(got) == ins
+        outs = sorted(dst[src == v].tolist())
+        assert sorted(plan.out_dst[plan.out_ptr[v]:plan.out_ptr[v + 1]].tolist()) == outs
+    # out_slot points at the same edge in the in-CSR
+    for v in range(N):
+        for e in range(int(plan.out_ptr[v]), int(plan.out_ptr[v + 1])):
+            sl = int(plan.out_slot[e])
+            assert int(plan.in_src[sl]) == v and int(plan.in_dst[sl]) == int(plan.out_dst[e])
+    # tiles: single slot, single level, cover every updated node exactly once, levels ascending
+    gate = g['gate'].reshape(-1).astype(int)
+    lv = g['forward_level']
+    slot_of = {3: 0, 2: 1, 5: 2, 1: 3, 4: 4}
+    seen = []
+    for lvl in range(plan.num_levels):
+        for t in range(plan.level_tile_ptr[lvl], plan.level_tile_ptr[lvl + 1]):
+            s, c, sl = int(plan.tile_start[t]), int(plan.tile_count[t]), int(plan.tile_slot[t])
+            assert 1 <= c <= 64
+            nodes = plan.order[s:s + c].tolist()
+            assert all(lv[n] == lvl and slot_of[gate[n]] == sl for n in nodes)
+            seen += nodes
+    want = [n for n in range(N) if lv[n] >= 1 and gate[n] in slot_of]
+    assert sorted(seen) == want and plan.level_tile_ptr[1] == 0
+    assert all(int(plan.gslot[n]) == (slot_of[gate[n]] if n in set(want) else 255) for n in range(N))
+
+
+def test_graph_plan_rejects_non_topological_levels():
+    ei = torch.tensor([[0, 1], [1, 2]])
+    with pytest.raises(ValueError):
+        GraphPlan(ei, 3).set_levels(torch.tensor([[0.], [1.], [1.]]), torch.tensor([0, 1, 1]), [1])
+
+
+def test_loader_rank_striding_matches_distributed_sampler():
+    graphs = [syn.make_graph('aig', 64, 3, i, n_inputs=4) for i in range(10)]
+    seen = []
+    for r in range(2):
+        ld = deepgate.GraphLoader(graphs, batch_size=2, shuffle=False, rank=r, world_size=2)
+        assert len(ld) == 2
+        for b in ld:
+            assert b.num_nodes == 128 and b.edge_index.max() < 128
+            seen.append(int(b.prob.shape[0]))
+    assert len(seen) == 4
+    smp = torch.utils.data.distributed.DistributedSampler(graphs, num_replicas=2, rank=1, shuffle=False)
+    ld = deepgate.GraphLoader(graphs, batch_size=1, shuffle=False, rank=1, world_size=2)
+    assert list(smp) == ld._indices()
+
+
+def test_flat_adam_views_and_checkpoint_format():
+    m = torch.nn.Linear(5, 3)
+    opt = deepgate.FlatAdam(m.parameters(), lr=1e-3)
+    f = opt.flat_buffers()
+    assert m.weight.data_ptr() == f['param'].data_ptr() and m.weight.grad.data_ptr() == f['grad'].data_ptr()
+    m(torch.ones(2, 5)).sum().backward()
+    assert float(f['grad'].abs().sum()) > 0           # autograd accumulated into the flat buffer
+    opt.zero_grad()
+    assert float(f['grad'].abs().sum()) == 0
+    sd = opt.state_dict()
+    ref = torch.optim.Adam(torch.nn.Linear(5, 3).parameters(), lr=1e-3).state_dict()
+    assert set(ref['param_groups'][0]) <= set(sd['param_groups'][0]) | {'decoupled_weight_decay'}
+    assert sd['param_groups'][0]['params'] == [0, 1]
+
+
+_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'multi-gate-vae_amd'))
+import deepgate
+from deepgate import synthetic as syn
+from oracle import ref_cpu as R
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', init_method='env://')
+z = np.load(os.path.join(sys.argv[1], 'tests', 'golden', 'g1_aig.npz'))
+
+def shard_grads(r):
+    p = R.params_from_npz(z)
+    g = syn.collate([syn.make_graph('aig', 40, 5, 300 + r, n_inputs=5)])
+    b = R.batch_from_arrays(lambda k: g[k])
+    bn = {k: v.clone() for k, v in p.items() if 'running_' in k}
+    ls = R.run_batch(p, 'aig', b, training=True, bn_state=bn, p_drop=0.0, s_rounds=2, t_rounds=2)
+    R.weighted_loss(ls, [1.0, 4.0, 4.0]).backward()
+    return p
+
+p = shard_grads(rank)
+names = [k for k, v in p.items() if v.requires_grad]
+params = [torch.nn.Parameter(p[k].detach().clone()) for k in names]
+for q, k in zip(params, names):
+    q.grad = p[k].grad.clone() if p[k].grad is not None else torch.zeros_like(q)
+opt = deepgate.FlatAdam(params, lr=1e-4)
+scale = opt.reduce_gradients()
+assert abs(scale - 1.0 / world) < 1e-12
+if rank == 0:
+    others = [shard_grads(r) for r in range(world)]
+    for q, k in zip(params, names):
+        mean = sum((o[k].grad if o[k].grad is not None else torch.zeros_like(o[k])) for o in others) / world
+        assert torch.allclose(q.grad * scale, mean, rtol=1e-6, atol=1e-9), k
+    print('EXCHANGE_OK')
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gradient_exchange_is_the_mean_of_shard_gradients(tmp_path):
+    """N>1 path on CPU: 2 processes over gloo, each with its own graphs; after the single flat
+    all-reduce every rank holds the arithmetic mean of the per-shard oracle gradients."""
+    script = tmp_path / 'worker.py'
+    script.write_text(_WORKER)
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), str(script), ROOT]
+    env = dict(os.environ, OMP_NUM_THREADS='2')
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'EXCHANGE_OK' in out.stdout
