@@ -54,6 +54,21 @@ int mgv_struct_stage_bwd(int H, int64_t N, const float* h_in, const int32_t* nbr
                          const float* gy_agg, float* g_direct_out, float* g_agg_out, float* dWc, float* dbc,
                          float* dWhh, float* dbhh, float* dxtab, float* dln_w, float* dln_b, void* stream);
 
+/* ---- the same half round on bf16x3 split-precision MFMA (hi/lo bf16 planes, three products, fp32
+ * accumulate; H in {32, 64}).  wpack_bf16 = eight bf16 blocks of 3H*H elements each:
+ * Wc_hi, Wc_lo, Whh_hi, Whh_lo ([3H][H]) then WcT_hi, WcT_lo, WhhT_hi, WhhT_lo ([H][3H]);
+ * hi = bf16(W), lo = bf16(W - hi).  All other arguments as for the fp32 entry points. */
+int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
+                            const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
+                            const float* bhh, const float* ln_w, const float* ln_b, float ln_eps, float* h_out,
+                            void* stream);
+int mgv_struct_stage_bwd_x3(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
+                            const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
+                            const float* bhh, const float* ln_w, const float* ln_b, float ln_eps,
+                            const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
+                            float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
+                            float* dln_b, void* stream);
+
 /* ---- Linear over node rows (hs_linear dg_ae_model_aig.py:64, hs_decompose :109, fc_{s,t}_{mu,logstd}
  * digvae_model.py:135-136, readout Linear layers mlp.py:29,38; also the dgrad with W^T):
  *   Y[N][M] = [X1 | X2] W^T + b     (X2/K2 = NULL/0 unless a torch.cat of two inputs is fused, :64)
@@ -102,9 +117,13 @@ int mgv_edge_dot_bwd(int H, int64_t E, const float* s, const float* t, int ld, c
 int mgv_recon_loss_fwd(int H, const float* s, const float* t, int ld, const int64_t* pos_src, const int64_t* pos_dst,
                        int64_t Epos, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
                        double* sums, uint64_t* counts, int32_t* pred_bin, void* stream);
-/* ds/dt += dL/ds, dL/dt for loss = sums[0]/Epos + sums[1]/Eneg scaled by the DEVICE scalar *gscale */
-int mgv_recon_loss_bwd(int H, const float* s, const float* t, int ld, const int64_t* pos_src, const int64_t* pos_dst,
-                       int64_t Epos, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
+/* ds/dt += dL/ds, dL/dt for loss = sums[0]/Epos + sums[1]/Eneg scaled by the DEVICE scalar *gscale.
+ * When the positive edges are the batch graph's own edges pass its two int32 CSRs (pos_out_* by
+ * source, pos_in_* by destination): the positive half then runs as gathers without atomics;
+ * NULL CSRs = arbitrary positive list, float atomics (one whole row per wave-instruction). */
+int mgv_recon_loss_bwd(int H, int64_t N, const float* s, const float* t, int ld, const int64_t* pos_src, const int64_t* pos_dst,
+                       int64_t Epos, const int32_t* pos_out_ptr, const int32_t* pos_out_dst, const int32_t* pos_in_ptr,
+                       const int32_t* pos_in_src, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
                        const float* gscale, float* ds, float* dt, void* stream);
 
 /* ---- functional-similarity loss (trainer.py:158-163, utils/utils.py:32-36): dis = 1 - cos(hf[a], hf[b]),

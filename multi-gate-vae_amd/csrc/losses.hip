@@ -114,6 +114,64 @@ __global__ __launch_bounds__(kThreads) void k_recon(ReconArgs a) {
     }
 }
 
+// Backward of the reconstruction loss, node-centric over the batch graph's two CSRs: the positive
+// edges ARE the graph edges, so  ds[u] = sum_{v in out(u)} c(u,v) t[v]  and  dt[v] = sum_{u in in(v)}
+// c(u,v) s[u]  are gathers (each edge's score is recomputed from both ends); no atomics, every output
+// row is written once, whole.
+template <int H>
+__global__ __launch_bounds__(kThreads) void k_recon_bwd_pull(int64_t N, const float* s, const float* t, int ld,
+                                                             const int32_t* out_ptr, const int32_t* out_dst,
+                                                             const int32_t* in_ptr, const int32_t* in_src, int64_t Ep,
+                                                             const float* gscale, float* ds, float* dt) {
+    constexpr int LPR = H / 4, RPB = kThreads / LPR;
+    const int lr = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+    const float w = -(*gscale) / (float)Ep;
+    for (int64_t n0 = (int64_t)blockIdx.x * RPB; n0 < N; n0 += (int64_t)gridDim.x * RPB) {
+        const int64_t u = n0 + slot;
+        if (u >= N) continue;
+        const float4 su = ld4(s + u * ld + 4 * lr), tu = ld4(t + u * ld + 4 * lr);
+        float4 gs = zero4(), gt = zero4();
+        for (int e = out_ptr[u]; e < out_ptr[u + 1]; ++e) {          // u as a source
+            const float4 tv = ld4(t + (int64_t)out_dst[e] * ld + 4 * lr);
+            const float p = sigmoidf_(group_sum<LPR>(dot4(su, tv)));
+            gs = fma4(w * p * (1.0f - p) / (p + 1e-15f), tv, gs);
+        }
+        for (int e = in_ptr[u]; e < in_ptr[u + 1]; ++e) {            // u as a destination
+            const float4 sv = ld4(s + (int64_t)in_src[e] * ld + 4 * lr);
+            const float p = sigmoidf_(group_sum<LPR>(dot4(sv, tu)));
+            gt = fma4(w * p * (1.0f - p) / (p + 1e-15f), sv, gt);
+        }
+        float* pds = ds + u * ld + 4 * lr;
+        float* pdt = dt + u * ld + 4 * lr;
+        st4(pds, add4(ld4(pds), gs));
+        st4(pdt, add4(ld4(pdt), gt));
+    }
+}
+
+// Arbitrary edge lists (the sampled negatives): one edge per H-lane group, one float per lane, so every
+// atomic wave-instruction adds whole contiguous rows (the shape the memory-side atomic units like).
+template <int H>
+__global__ __launch_bounds__(kThreads) void k_recon_bwd_rows(int64_t E, const float* s, const float* t, int ld, const int64_t* src,
+                                                             const int64_t* dst, int negative, float wscale, const float* gscale,
+                                                             float* ds, float* dt) {
+    constexpr int EPB = kThreads / H;
+    const int l = threadIdx.x % H, slot = threadIdx.x / H;
+    const float w = (*gscale) * wscale;
+    for (int64_t e0 = (int64_t)blockIdx.x * EPB; e0 < E; e0 += (int64_t)gridDim.x * EPB) {
+        const int64_t e = e0 + slot;
+        const bool ok = e < E;
+        int64_t u = 0, v = 0;
+        float x = 0.f, y = 0.f;
+        if (ok) { u = src[e]; v = dst[e]; x = s[u * ld + l]; y = t[v * ld + l]; }
+        const float p = sigmoidf_(group_sum<H>(x * y));
+        if (!ok) continue;
+        const float dp = p * (1.0f - p);
+        const float c = negative ? w * dp / ((1.0f - p) + 1e-15f) : -w * dp / (p + 1e-15f);
+        atomicAdd(ds + u * ld + l, c * y);
+        atomicAdd(dt + v * ld + l, c * x);
+    }
+}
+
 // ---------------------------------------------------------------------------------- functional loss
 // ws (double[8]): 0 sum d, 1 sum d^2, 2 sum t, 3 sum t^2, 4 sum |zd - zt|, 5 sum sgn, 6 sum sgn*zd
 template <int H>
@@ -313,17 +371,32 @@ extern "C" int mgv_recon_loss_fwd(int H, const float* s, const float* t, int ld,
     MGV_LAUNCH_RET();
 }
 
-extern "C" int mgv_recon_loss_bwd(int H, const float* s, const float* t, int ld, const int64_t* pos_src, const int64_t* pos_dst,
-                                  int64_t Epos, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
+extern "C" int mgv_recon_loss_bwd(int H, int64_t N, const float* s, const float* t, int ld, const int64_t* pos_src, const int64_t* pos_dst,
+                                  int64_t Epos, const int32_t* pos_out_ptr, const int32_t* pos_out_dst, const int32_t* pos_in_ptr,
+                                  const int32_t* pos_in_src, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
                                   const float* gscale, float* ds, float* dt, void* stream) {
-    MGV_CHECK_ARG(s && t && gscale && ds && dt && Epos >= 0 && Eneg >= 0 && ld >= H && ld % 4 == 0);
+    MGV_CHECK_ARG(s && t && gscale && ds && dt && Epos >= 0 && Eneg >= 0 && N >= 0 && ld >= H && ld % 4 == 0);
     MGV_CHECK_ARG((Epos == 0 || (pos_src && pos_dst)) && (Eneg == 0 || (neg_src && neg_dst)));
-    if (Epos + Eneg == 0) return MGV_OK;
-    mgv::ReconArgs a{};
-    a.s = s; a.t = t; a.ld = ld; a.psrc = pos_src; a.pdst = pos_dst; a.Ep = Epos; a.nsrc = neg_src; a.ndst = neg_dst; a.En = Eneg;
-    a.gscale = gscale; a.ds = ds; a.dt = dt;
+    const bool pull = pos_out_ptr != nullptr;
+    MGV_CHECK_ARG(!pull || (pos_in_ptr && (Epos == 0 || (pos_out_dst && pos_in_src))));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_recon<HH, true>), dim3(mgv::items_grid(Epos + Eneg, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st, a));
+    if (Epos > 0 && pull) {
+        MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_recon_bwd_pull<HH>), dim3(mgv::items_grid(N, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st,
+                                             N, s, t, ld, pos_out_ptr, pos_out_dst, pos_in_ptr, pos_in_src, Epos, gscale, ds, dt));
+    }
+    for (int neg = (Epos > 0 && pull) ? 1 : 0; neg < 2; ++neg) {
+        const int64_t E = neg ? Eneg : Epos;
+        if (E == 0) continue;
+        const int64_t* es = neg ? neg_src : pos_src;
+        const int64_t* ed = neg ? neg_dst : pos_dst;
+        const float wsc = 1.0f / (float)E;
+        switch (H) {     // one float per lane: the row must fit a wave
+            case 16: hipLaunchKernelGGL((mgv::k_recon_bwd_rows<16>), dim3(mgv::items_grid(E, mgv::kThreads / 16)), dim3(mgv::kThreads), 0, st, E, s, t, ld, es, ed, neg, wsc, gscale, ds, dt); break;
+            case 32: hipLaunchKernelGGL((mgv::k_recon_bwd_rows<32>), dim3(mgv::items_grid(E, mgv::kThreads / 32)), dim3(mgv::kThreads), 0, st, E, s, t, ld, es, ed, neg, wsc, gscale, ds, dt); break;
+            case 64: hipLaunchKernelGGL((mgv::k_recon_bwd_rows<64>), dim3(mgv::items_grid(E, mgv::kThreads / 64)), dim3(mgv::kThreads), 0, st, E, s, t, ld, es, ed, neg, wsc, gscale, ds, dt); break;
+            default: return MGV_EUNSUPPORTED;
+        }
+    }
     MGV_LAUNCH_RET();
 }
 

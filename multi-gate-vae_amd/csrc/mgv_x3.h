@@ -1,0 +1,48 @@
+// Split-precision ("bf16x3") matrix products: an fp32 operand x is carried as two bf16 planes
+// hi = bf16(x), lo = bf16(x - hi) and a product as  lo*hi + hi*lo + hi*hi  on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  The dropped lo*lo term and the 2^-17 truncation
+// of the split leave ~1e-5 relative error per product (measured on the reference fixtures: losses
+// move by ~1e-6, embeddings by ~3e-5) at 3/16 of the fp32-MFMA cost.
+#pragma once
+#include "mgv_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace mgv {
+
+__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)x;
+    lo = (__bf16)(x - (float)hi);
+}
+
+__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
+    __bf16 h0, h1, h2, h3, l0, l1, l2, l3;
+    split_bf16(v.x, h0, l0); split_bf16(v.y, h1, l1); split_bf16(v.z, h2, l2); split_bf16(v.w, h3, l3);
+    hi = bf16x4{h0, h1, h2, h3};
+    lo = bf16x4{l0, l1, l2, l3};
+}
+
+__device__ __forceinline__ bf16x8 ldfrag(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void st_bf4(__bf16* p, const bf16x4& v) { *reinterpret_cast<bf16x4*>(p) = v; }
+
+__device__ __forceinline__ f32x4 mfma_bf16(const bf16x8& a, const bf16x8& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// c += (a_hi + a_lo) . (b_hi + b_lo) over a 32-deep k-step, small terms first
+__device__ __forceinline__ void mma_x3(f32x4& c, const bf16x8& ahi, const bf16x8& alo, const bf16x8& bhi, const bf16x8& blo) {
+    c = mfma_bf16(alo, bhi, c);
+    c = mfma_bf16(ahi, blo, c);
+    c = mfma_bf16(ahi, bhi, c);
+}
+
+// bf16 LDS planes: [rows][K] with K+8 elements per row (144-byte rows at K=64: the 16 rows a
+// ds_read_b128 fragment touches start 36 dwords apart, i.e. on distinct 4-bank groups)
+template <int K>
+struct Plane {
+    static constexpr int LD = K + 8;
+    static constexpr int ELEMS = kTileRows * LD;
+};
+
+}  // namespace mgv

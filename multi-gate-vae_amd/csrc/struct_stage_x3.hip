@@ -1,0 +1,768 @@
+// Structural-encoder half round on bf16x3 split-precision MFMA (see mgv_x3.h); same math, arguments
+// and phases as struct_stage.hip, whose header describes the operator.  With the dense part 5x
+// cheaper the kernel is bound by the row gathers: HBM bytes per node and half round are unchanged
+// (forward (deg+2)*4H, backward (2deg+4)*4H).
+//
+// Weights arrive pre-split by the host in one bf16 pack of eight [3H*H] blocks:
+//   0 Wc_hi  1 Wc_lo  2 Whh_hi  3 Whh_lo   ([3H][H], k contiguous: forward B operands)
+//   4 WcT_hi 5 WcT_lo 6 WhhT_hi 7 WhhT_lo  ([H][3H], k contiguous: dgrad B operands)
+#include "mgv_x3.h"
+#include "../../include/mgvae_hip.h"
+
+namespace mgv {
+
+struct StageX3Args {
+    unsigned long long* stamps;   // diagnostic build only (MGV_STAMPS): [8 waves][16 phases] cycle sums
+    int64_t N;
+    const float* h_in;
+    const int32_t* ptr;
+    const int32_t* idx;
+    const uint8_t* xcls;
+    const float* xtab;
+    int C;
+    const __bf16* wpack;
+    const float* bc;
+    const float* bhh;
+    const float* lnw;
+    const float* lnb;
+    float eps;
+    float* h_out;
+    const float* gy_direct;
+    const float* gy_agg;
+    float* g_direct_out;
+    float* g_agg_out;
+    float* dWc; float* dbc; float* dWhh; float* dbhh; float* dxtab; float* dlnw; float* dlnb;
+};
+
+#ifdef MGV_STAMPS
+// in-kernel phase stamps (diagnostic build only; never quote its run time, read the SHARES)
+#define STAMP_DECL unsigned long long st_t0_ = 0, st_acc_[16] = {0}; int st_k_ = 0;
+#define STAMP_BEGIN do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st_k_ = 0; } while (0)
+#define STAMP(k) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st_acc_[k] += t_ - st_t0_; st_t0_ = t_; } while (0)
+#define STAMP_FLUSH(a) do { if ((threadIdx.x & 63) == 0 && (a).stamps) for (int k_ = 0; k_ < 16; ++k_) atomicAdd((a).stamps + (threadIdx.x >> 6) * 16 + k_, st_acc_[k_]); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP_BEGIN
+#define STAMP(k)
+#define STAMP_FLUSH(a)
+#endif
+
+constexpr int kMaxClsX3 = 8;
+constexpr int LDT = kTileRows + 8;      // transposed planes: [H][64 tile rows (+8 pad)]
+constexpr int kNW = 8;                  // waves per workgroup (two per SIMD)
+constexpr int kThreadsX3 = kNW * 64;
+constexpr int kIdxCap = 1024;           // neighbour entries of one tile kept in LDS; the tail is read from global
+constexpr int kIdxRegs = kIdxCap / kThreadsX3;
+constexpr int kPtrPad = 80;             // 65 CSR pointers of a tile, padded
+
+// 8 waves over a (64 rows) x (H hidden columns) output: across column tiles first, then row tiles
+template <int H>
+struct SplitX3 {
+    static constexpr int HC = H / 16;
+    static constexpr int WPC = HC < 4 ? HC : 4;
+    static constexpr int WPR = kNW / WPC;
+    static constexpr int RTW = 4 / WPR;
+    static_assert(RTW >= 1, "too many waves for the tile");
+    static constexpr int HCW = HC / WPC;
+    static constexpr int LD = H + 4;
+    static constexpr int LPR = H / 4;
+    static constexpr int GROUPS = kThreadsX3 / LPR;
+};
+
+template <int H>
+struct X3Smem {
+    using S = SplitX3<H>;
+    static constexpr int LDP = H + 8;                         // bf16 elements per row-major plane row
+    static constexpr int PB = kTileRows * LDP * 2;            // bytes of a row-major plane
+    static constexpr int PT = H * LDT * 2;                    // bytes of a transposed plane
+    static constexpr int F32TILE = kTileRows * S::LD * 4;
+    static constexpr int SMALL_F = kMaxClsX3 * 3 * H + 3 * H + 3 * H + H + H + kTileRows + kTileRows;   // floats
+    // forward
+    static constexpr int f_planes = 0;                        // agg_hi, agg_lo, hin_hi, hin_lo
+    static constexpr int f_hin = f_planes + 4 * PB;           // fp32 own rows
+    static constexpr int f_pre = f_planes;                    // fp32 pre-LayerNorm rows: reuse the agg planes once the MFMAs are done
+    static_assert(F32TILE <= 2 * PB, "pre-LN tile must fit the two agg planes");
+    static constexpr int f_small = f_hin + F32TILE;
+    static constexpr int IDX_BYTES = 2 * (kPtrPad + kIdxCap) * 4;
+    static constexpr int f_idx = f_small + SMALL_F * 4;
+    static constexpr int fwd_bytes = f_idx + IDX_BYTES;
+    // backward
+    static constexpr int b_planes = 0;                        // region A: row-major operand planes
+    static constexpr int b_tplanes = b_planes + 4 * PB;       // region B: transposed aggT_hi/lo, hinT_hi/lo
+    static constexpr int b_c = b_tplanes + 4 * PT;            // region C: {pre, dy fp32} then {d_hi, d_lo, dT_hi, dT_lo}
+    static constexpr int C_BYTES = (2 * F32TILE > 2 * PB + 2 * PT) ? 2 * F32TILE : 2 * PB + 2 * PT;
+    static constexpr int b_small = b_c + C_BYTES;
+    static constexpr int b_stat = b_small + SMALL_F * 4;      // 4 floats per row
+    static constexpr int b_acc = b_stat + 4 * kTileRows * 4;  // dxt[C*3H], dbc[3H], dbhh[3H], dlnw[H], dlnb[H]
+    static constexpr int ACC_F = kMaxClsX3 * 3 * H + 3 * H + 3 * H + H + H;
+    static constexpr int b_idx = b_acc + ACC_F * 4;
+    static constexpr int bwd_bytes = b_idx + IDX_BYTES;
+    static_assert(bwd_bytes <= 160 * 1024, "backward LDS budget");
+};
+
+struct SmallVecs {
+    const float* xtab; const float* bc; const float* bhh; const float* lnw; const float* lnb; float* deg; int* cls;
+};
+
+template <int H>
+__device__ __forceinline__ SmallVecs stage_small(const StageX3Args& a, float* base) {
+    SmallVecs v;
+    float* xtab = base;
+    float* bc = xtab + kMaxClsX3 * 3 * H;
+    float* bhh = bc + 3 * H;
+    float* lnw = bhh + 3 * H;
+    float* lnb = lnw + H;
+    float* deg = lnb + H;
+    int* cls = reinterpret_cast<int*>(deg + kTileRows);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < a.C * 3 * H; i += kThreadsX3) xtab[i] = a.xtab[i];
+    for (int i = tid; i < 3 * H; i += kThreadsX3) { bc[i] = a.bc[i]; bhh[i] = a.bhh[i]; }
+    for (int i = tid; i < H; i += kThreadsX3) { lnw[i] = a.lnw ? a.lnw[i] : 1.0f; lnb[i] = a.lnb ? a.lnb[i] : 0.0f; }
+    v.xtab = xtab; v.bc = bc; v.bhh = bhh; v.lnw = lnw; v.lnb = lnb; v.deg = deg; v.cls = cls;
+    return v;
+}
+
+
+// ---- neighbour-index prefetch.  The row gathers are the only HBM-latency-bound part of the kernel, so
+// the CSR pointers and indices of tile t+1 are fetched while tile t is being computed and parked in LDS;
+// the row phase of a tile then consists of independent loads only (own rows + up to 4 neighbour rows
+// per lane group in flight at once).
+struct IdxLds { int* ptr; int* idx; };   // one of two LDS buffers
+
+__device__ __forceinline__ int ptr_prefetch(const StageX3Args& a, int64_t tile, int64_t ntiles) {
+    if (tile >= ntiles || threadIdx.x > kTileRows) return 0;
+    int64_t n = tile * kTileRows + threadIdx.x;
+    n = n < a.N ? n : a.N;
+    return a.ptr[n];
+}
+
+__device__ __forceinline__ void idx_prefetch(const StageX3Args& a, const int* s_ptr, int (&ri)[kIdxRegs]) {
+    const int e0 = s_ptr[0], ne = s_ptr[kTileRows] - e0;
+#pragma unroll
+    for (int k = 0; k < kIdxRegs; ++k) {
+        const int i = threadIdx.x + k * kThreadsX3;
+        ri[k] = i < ne ? a.idx[e0 + i] : 0;
+    }
+}
+
+__device__ __forceinline__ void idx_commit(int* s_idx, const int (&ri)[kIdxRegs]) {
+#pragma unroll
+    for (int k = 0; k < kIdxRegs; ++k) s_idx[threadIdx.x + k * kThreadsX3] = ri[k];
+}
+
+__device__ __forceinline__ int idx_at(const StageX3Args& a, const int* s_ptr, const int* s_idx, int e) {
+    const int rel = e - s_ptr[0];
+    return rel < kIdxCap ? s_idx[rel] : a.idx[e];
+}
+
+// all row loads of one tile row: own row (+ incoming gradient), neighbour sums of h_in (+ of gy_agg)
+template <int H, bool DY>
+__device__ __forceinline__ void row_gather(const StageX3Args& a, int64_t node, int row, int lr, const int* s_ptr, const int* s_idx,
+                                           float4& acc, float4& own, float4& dy, float& deg, int& cls) {
+    acc = zero4(); own = zero4(); dy = zero4(); deg = 0.f; cls = 0;
+    if (node >= a.N) return;
+    const int p0 = s_ptr[row], p1 = s_ptr[row + 1];
+    deg = (float)(p1 - p0);
+    own = ld4(a.h_in + node * H + 4 * lr);
+    if (DY) dy = ld4(a.gy_direct + node * H + 4 * lr);
+    cls = a.xcls[node];
+    const bool two = DY && a.gy_agg != nullptr;
+    for (int e = p0; e < p1; e += 4) {
+        const int d = p1 - e;
+        float4 v0 = zero4(), v1 = zero4(), v2 = zero4(), v3 = zero4();
+        float4 g0 = zero4(), g1 = zero4(), g2 = zero4(), g3 = zero4();
+        const int64_t j0 = idx_at(a, s_ptr, s_idx, e);
+        const int64_t j1 = d > 1 ? idx_at(a, s_ptr, s_idx, e + 1) : 0;
+        const int64_t j2 = d > 2 ? idx_at(a, s_ptr, s_idx, e + 2) : 0;
+        const int64_t j3 = d > 3 ? idx_at(a, s_ptr, s_idx, e + 3) : 0;
+        v0 = ld4(a.h_in + j0 * H + 4 * lr);
+        if (d > 1) v1 = ld4(a.h_in + j1 * H + 4 * lr);
+        if (d > 2) v2 = ld4(a.h_in + j2 * H + 4 * lr);
+        if (d > 3) v3 = ld4(a.h_in + j3 * H + 4 * lr);
+        if (two) {
+            g0 = ld4(a.gy_agg + j0 * H + 4 * lr);
+            if (d > 1) g1 = ld4(a.gy_agg + j1 * H + 4 * lr);
+            if (d > 2) g2 = ld4(a.gy_agg + j2 * H + 4 * lr);
+            if (d > 3) g3 = ld4(a.gy_agg + j3 * H + 4 * lr);
+        }
+        acc = add4(acc, add4(add4(v0, v1), add4(v2, v3)));
+        if (two) dy = add4(dy, add4(add4(g0, g1), add4(g2, g3)));
+    }
+}
+
+// gate pre-activations of one tile from the split planes; weights streamed from L2
+template <int H>
+__device__ __forceinline__ void stage_gemm_x3(const __bf16* wpack, const __bf16* agg_hi, const __bf16* agg_lo,
+                                              const __bf16* hin_hi, const __bf16* hin_lo,
+                                              f32x4 (&ar)[SplitX3<H>::RTW][SplitX3<H>::HCW],
+                                              f32x4 (&az)[SplitX3<H>::RTW][SplitX3<H>::HCW],
+                                              f32x4 (&ani)[SplitX3<H>::RTW][SplitX3<H>::HCW],
+                                              f32x4 (&anh)[SplitX3<H>::RTW][SplitX3<H>::HCW]) {
+    using S = SplitX3<H>;
+    constexpr int LDP = H + 8, BLK = 3 * H * H;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    const int wc = w % S::WPC, wr = w / S::WPC;
+#pragma unroll
+    for (int i = 0; i < S::RTW; ++i)
+#pragma unroll
+        for (int j = 0; j < S::HCW; ++j) {
+            ar[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; az[i][j] = ar[i][j]; ani[i][j] = ar[i][j]; anh[i][j] = ar[i][j];
+        }
+#pragma unroll 1
+    for (int ks = 0; ks < H / 32; ++ks) {
+        const int ko = 32 * ks + 8 * q;
+        bf16x8 ah[S::RTW], al[S::RTW], hh[S::RTW], hl[S::RTW];
+#pragma unroll
+        for (int i = 0; i < S::RTW; ++i) {
+            const int off = ((wr * S::RTW + i) * 16 + r) * LDP + ko;
+            ah[i] = ldfrag(agg_hi + off); al[i] = ldfrag(agg_lo + off);
+            hh[i] = ldfrag(hin_hi + off); hl[i] = ldfrag(hin_lo + off);
+        }
+#pragma unroll
+        for (int j = 0; j < S::HCW; ++j) {
+            const int col = (wc * S::HCW + j) * 16 + r;
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const int64_t wo = (int64_t)(g * H + col) * H + ko;
+                const bf16x8 ch = ldfrag(wpack + 0 * BLK + wo), cl = ldfrag(wpack + 1 * BLK + wo);
+                const bf16x8 uh = ldfrag(wpack + 2 * BLK + wo), ul = ldfrag(wpack + 3 * BLK + wo);
+#pragma unroll
+                for (int i = 0; i < S::RTW; ++i) {
+                    if (g == 0) { mma_x3(ar[i][j], ah[i], al[i], ch, cl); mma_x3(ar[i][j], hh[i], hl[i], uh, ul); }
+                    if (g == 1) { mma_x3(az[i][j], ah[i], al[i], ch, cl); mma_x3(az[i][j], hh[i], hl[i], uh, ul); }
+                    if (g == 2) { mma_x3(ani[i][j], ah[i], al[i], ch, cl); mma_x3(anh[i][j], hh[i], hl[i], uh, ul); }
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep one gate's weight fragments live at a time
+            }
+        }
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(kThreadsX3, 4) void k_struct_stage_fwd_x3(StageX3Args a) {
+    using S = SplitX3<H>;
+    using M = X3Smem<H>;
+    constexpr int LDP = M::LDP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* agg_hi = reinterpret_cast<__bf16*>(smem_raw + M::f_planes);
+    __bf16* agg_lo = reinterpret_cast<__bf16*>(smem_raw + M::f_planes + M::PB);
+    __bf16* hin_hi = reinterpret_cast<__bf16*>(smem_raw + M::f_planes + 2 * M::PB);
+    __bf16* hin_lo = reinterpret_cast<__bf16*>(smem_raw + M::f_planes + 3 * M::PB);
+    float* s_hin = reinterpret_cast<float*>(smem_raw + M::f_hin);
+    float* s_pre = reinterpret_cast<float*>(smem_raw + M::f_pre);
+    const SmallVecs sv = stage_small<H>(a, reinterpret_cast<float*>(smem_raw + M::f_small));
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int wc = w % S::WPC, wr = w / S::WPC;
+    const int grp = tid / S::LPR, lr = tid % S::LPR;
+    const bool has_ln = a.lnw != nullptr;
+    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+    int* idx_base = reinterpret_cast<int*>(smem_raw + M::f_idx);
+    IdxLds ib[2] = {{idx_base, idx_base + kPtrPad}, {idx_base + kPtrPad + kIdxCap, idx_base + 2 * kPtrPad + kIdxCap}};
+    // prologue: indices of this workgroup's first tile, pointers of its second
+    int rp = ptr_prefetch(a, blockIdx.x, ntiles);
+    if (tid <= kTileRows) ib[0].ptr[tid] = rp;
+    __syncthreads();
+    int ri[kIdxRegs];
+    idx_prefetch(a, ib[0].ptr, ri);
+    idx_commit(ib[0].idx, ri);
+    rp = ptr_prefetch(a, (int64_t)blockIdx.x + gridDim.x, ntiles);
+    __syncthreads();
+    int b = 0;
+    STAMP_DECL
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, b ^= 1) {
+        const int64_t base = tile * kTileRows;
+        STAMP_BEGIN;
+        // ---- row phase: independent loads only
+#pragma unroll
+        for (int rr = 0; rr < kTileRows / S::GROUPS; ++rr) {
+            const int row = grp + rr * S::GROUPS;
+            float4 acc, own, dy;
+            float deg;
+            int cls;
+            row_gather<H, false>(a, base + row, row, lr, ib[b].ptr, ib[b].idx, acc, own, dy, deg, cls);
+            bf16x4 hi, lo;
+            split4(acc, hi, lo);
+            st_bf4(agg_hi + row * LDP + 4 * lr, hi); st_bf4(agg_lo + row * LDP + 4 * lr, lo);
+            split4(own, hi, lo);
+            st_bf4(hin_hi + row * LDP + 4 * lr, hi); st_bf4(hin_lo + row * LDP + 4 * lr, lo);
+            st4(s_hin + row * S::LD + 4 * lr, own);
+            if (lr == 0) { sv.deg[row] = deg; sv.cls[row] = cls; }
+        }
+        if (tid <= kTileRows) ib[b ^ 1].ptr[tid] = rp;       // pointers of the next tile (loaded one tile ago)
+        STAMP(0);
+        __syncthreads();
+        STAMP(1);
+        idx_prefetch(a, ib[b ^ 1].ptr, ri);                   // in flight during the dense part
+        rp = ptr_prefetch(a, tile + 2 * (int64_t)gridDim.x, ntiles);
+        f32x4 ar[S::RTW][S::HCW], az[S::RTW][S::HCW], ani[S::RTW][S::HCW], anh[S::RTW][S::HCW];
+        stage_gemm_x3<H>(a.wpack, agg_hi, agg_lo, hin_hi, hin_lo, ar, az, ani, anh);
+        STAMP(2);
+        __syncthreads();        // s_pre overlays the agg planes
+        STAMP(3);
+#pragma unroll
+        for (int i = 0; i < S::RTW; ++i)
+#pragma unroll
+            for (int j = 0; j < S::HCW; ++j) {
+                const int col = (wc * S::HCW + j) * 16 + r;
+                const float bcr = sv.bc[col], bcz = sv.bc[H + col], bcn = sv.bc[2 * H + col];
+                const float bhr = sv.bhh[col], bhz = sv.bhh[H + col], bhn = sv.bhh[2 * H + col];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
+                    const float deg = sv.deg[row];
+                    const float* xt = sv.xtab + sv.cls[row] * 3 * H;
+                    const float rr = sigmoidf_(ar[i][j][e] + deg * bcr + xt[col] + bhr);
+                    const float zz = sigmoidf_(az[i][j][e] + deg * bcz + xt[H + col] + bhz);
+                    const float nn = tanhf_(ani[i][j][e] + deg * bcn + xt[2 * H + col] + rr * (anh[i][j][e] + bhn));
+                    const float hp = s_hin[row * S::LD + col];
+                    s_pre[row * S::LD + col] = (1.0f - zz) * nn + zz * hp;
+                }
+            }
+        STAMP(4);
+        idx_commit(ib[b ^ 1].idx, ri);
+        STAMP(5);
+        __syncthreads();
+        STAMP(6);
+        for (int row = grp; row < kTileRows; row += S::GROUPS) {
+            const int64_t node = base + row;
+            float4 v = ld4(s_pre + row * S::LD + 4 * lr);
+            if (has_ln) {
+                const float mean = group_sum<S::LPR>(v.x + v.y + v.z + v.w) * (1.0f / H);
+                v = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+                const float var = group_sum<S::LPR>(dot4(v, v)) * (1.0f / H);
+                const float rstd = rsqrtf(var + a.eps);
+                const float4 g = ld4(sv.lnw + 4 * lr), b = ld4(sv.lnb + 4 * lr);
+                v = make_float4(v.x * rstd * g.x + b.x, v.y * rstd * g.y + b.y, v.z * rstd * g.z + b.z, v.w * rstd * g.w + b.w);
+            }
+            if (node < a.N) st4(a.h_out + node * H + 4 * lr, v);
+        }
+        STAMP(7);
+    }
+    STAMP_FLUSH(a);
+}
+
+// ------------------------------------------------------------------------------------------ backward
+template <int H>
+struct WgradX3 {
+    static constexpr int HC = H / 16;
+    static constexpr int T = HC * HC;
+    static_assert(T >= 4, "bf16x3 path needs H >= 32");
+    static constexpr bool KSPLIT = T < kNW;                 // fewer tiles than waves: waves share a tile, split the 64 rows
+    static constexpr int TPW = KSPLIT ? 1 : T / kNW;
+    static constexpr int KS = KSPLIT ? (kTileRows / 32) / (kNW / T) : kTileRows / 32;   // 32-row k-steps per wave
+    static_assert(KS >= 1, "k split too fine");
+    __device__ static int tile_of(int w, int t) { return KSPLIT ? w % T : w * TPW + t; }
+    __device__ static int ks0(int w) { return KSPLIT ? (w / T) * KS : 0; }
+};
+
+// acc[t] += D^T[gate cols of tile][64 rows] * X[64 rows][input cols of tile], both from transposed planes
+template <int H>
+__device__ __forceinline__ void wgrad_x3(f32x4 (&acc)[WgradX3<H>::TPW], const __bf16* dT_hi, const __bf16* dT_lo,
+                                         const __bf16* xT_hi, const __bf16* xT_lo) {
+    using W = WgradX3<H>;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+#pragma unroll 1
+    for (int kk = 0; kk < W::KS; ++kk) {
+        const int ko = 32 * (W::ks0(w) + kk) + 8 * q;
+#pragma unroll
+        for (int t = 0; t < W::TPW; ++t) {
+            const int tl = W::tile_of(w, t);
+            const int it = tl / W::HC, jt = tl % W::HC;
+            const bf16x8 ah = ldfrag(dT_hi + (it * 16 + r) * LDT + ko), al = ldfrag(dT_lo + (it * 16 + r) * LDT + ko);
+            const bf16x8 bh = ldfrag(xT_hi + (jt * 16 + r) * LDT + ko), bl = ldfrag(xT_lo + (jt * 16 + r) * LDT + ko);
+            mma_x3(acc[t], ah, al, bh, bl);
+        }
+    }
+}
+
+template <int H>
+__device__ __forceinline__ void wgrad_flush_x3(const f32x4 (&acc)[WgradX3<H>::TPW], float* dW) {
+    using W = WgradX3<H>;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < W::TPW; ++t) {
+        const int tl = W::tile_of(w, t);
+        const int it = tl / W::HC, jt = tl % W::HC;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(dW + (int64_t)(it * 16 + q * 4 + e) * H + jt * 16 + r, acc[t][e]);
+    }
+}
+
+__device__ __forceinline__ void colsum_lds_x3(float v, float* dst) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if ((threadIdx.x & 63) < 16) atomicAdd(dst, v);
+}
+
+template <int H>
+__global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args a) {
+    using S = SplitX3<H>;
+    using M = X3Smem<H>;
+    using W = WgradX3<H>;
+    constexpr int LDP = M::LDP, BLK = 3 * H * H;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* agg_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_planes);
+    __bf16* agg_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_planes + M::PB);
+    __bf16* hin_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_planes + 2 * M::PB);
+    __bf16* hin_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_planes + 3 * M::PB);
+    __bf16* aggT_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_tplanes);
+    __bf16* aggT_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_tplanes + M::PT);
+    __bf16* hinT_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_tplanes + 2 * M::PT);
+    __bf16* hinT_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_tplanes + 3 * M::PT);
+    float* s_pre = reinterpret_cast<float*>(smem_raw + M::b_c);
+    float* s_dy = reinterpret_cast<float*>(smem_raw + M::b_c + M::F32TILE);
+    __bf16* d_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_c);                       // aliases s_pre/s_dy
+    __bf16* d_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_c + M::PB);
+    __bf16* dT_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_c + 2 * M::PB);
+    __bf16* dT_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_c + 2 * M::PB + M::PT);
+    const SmallVecs sv = stage_small<H>(a, reinterpret_cast<float*>(smem_raw + M::b_small));
+    float* s_stat = reinterpret_cast<float*>(smem_raw + M::b_stat);
+    float* s_dxt = reinterpret_cast<float*>(smem_raw + M::b_acc);
+    float* s_dbc = s_dxt + kMaxClsX3 * 3 * H;
+    float* s_dbhh = s_dbc + 3 * H;
+    float* s_dlnw = s_dbhh + 3 * H;
+    float* s_dlnb = s_dlnw + H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+    for (int i = tid; i < M::ACC_F; i += kThreadsX3) s_dxt[i] = 0.f;
+    const int wc = w % S::WPC, wr = w / S::WPC;
+    const int grp = tid / S::LPR, lr = tid % S::LPR;
+    const bool has_ln = a.lnw != nullptr;
+    const bool need_dgrad = a.g_direct_out != nullptr;
+    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+
+    f32x4 gWc[3][W::TPW], gWhh[3][W::TPW];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int t = 0; t < W::TPW; ++t) { gWc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f}; gWhh[g][t] = gWc[g][t]; }
+    __syncthreads();
+
+    int* idx_base = reinterpret_cast<int*>(smem_raw + M::b_idx);
+    IdxLds ib[2] = {{idx_base, idx_base + kPtrPad}, {idx_base + kPtrPad + kIdxCap, idx_base + 2 * kPtrPad + kIdxCap}};
+    int rp = ptr_prefetch(a, blockIdx.x, ntiles);
+    if (tid <= kTileRows) ib[0].ptr[tid] = rp;
+    __syncthreads();
+    int ri[kIdxRegs];
+    idx_prefetch(a, ib[0].ptr, ri);
+    idx_commit(ib[0].idx, ri);
+    rp = ptr_prefetch(a, (int64_t)blockIdx.x + gridDim.x, ntiles);
+    __syncthreads();
+    int b = 0;
+    STAMP_DECL
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, b ^= 1) {
+        const int64_t base = tile * kTileRows;
+        STAMP_BEGIN;
+        // ---- A. row phase (independent loads); operand planes row-major (GEMM A operands) and
+        //        transposed (wgrad B operands)
+#pragma unroll
+        for (int rr = 0; rr < kTileRows / S::GROUPS; ++rr) {
+            const int row = grp + rr * S::GROUPS;
+            float4 acc, own, dy;
+            float deg;
+            int cls;
+            row_gather<H, true>(a, base + row, row, lr, ib[b].ptr, ib[b].idx, acc, own, dy, deg, cls);
+            bf16x4 hi, lo;
+            split4(acc, hi, lo);
+            st_bf4(agg_hi + row * LDP + 4 * lr, hi); st_bf4(agg_lo + row * LDP + 4 * lr, lo);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { aggT_hi[(4 * lr + c) * LDT + row] = hi[c]; aggT_lo[(4 * lr + c) * LDT + row] = lo[c]; }
+            split4(own, hi, lo);
+            st_bf4(hin_hi + row * LDP + 4 * lr, hi); st_bf4(hin_lo + row * LDP + 4 * lr, lo);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { hinT_hi[(4 * lr + c) * LDT + row] = hi[c]; hinT_lo[(4 * lr + c) * LDT + row] = lo[c]; }
+            st4(s_dy + row * S::LD + 4 * lr, dy);
+            if (lr == 0) { sv.deg[row] = deg; sv.cls[row] = cls; }
+        }
+        if (tid <= kTileRows) ib[b ^ 1].ptr[tid] = rp;
+        STAMP(0);
+        __syncthreads();
+        STAMP(1);
+        idx_prefetch(a, ib[b ^ 1].ptr, ri);
+        rp = ptr_prefetch(a, tile + 2 * (int64_t)gridDim.x, ntiles);
+        // ---- B. recompute gates; keep the own-row values (hi+lo) for the GRU backward
+        f32x4 ar[S::RTW][S::HCW], az[S::RTW][S::HCW], ani[S::RTW][S::HCW], anh[S::RTW][S::HCW];
+        stage_gemm_x3<H>(a.wpack, agg_hi, agg_lo, hin_hi, hin_lo, ar, az, ani, anh);
+        STAMP(2);
+#pragma unroll
+        for (int i = 0; i < S::RTW; ++i)
+#pragma unroll
+            for (int j = 0; j < S::HCW; ++j) {
+                const int col = (wc * S::HCW + j) * 16 + r;
+                const float bcr = sv.bc[col], bcz = sv.bc[H + col], bcn = sv.bc[2 * H + col];
+                const float bhr = sv.bhh[col], bhz = sv.bhh[H + col], bhn = sv.bhh[2 * H + col];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
+                    const float deg = sv.deg[row];
+                    const float* xt = sv.xtab + sv.cls[row] * 3 * H;
+                    const float rr = sigmoidf_(ar[i][j][e] + deg * bcr + xt[col] + bhr);
+                    const float zz = sigmoidf_(az[i][j][e] + deg * bcz + xt[H + col] + bhz);
+                    const float ghn = anh[i][j][e] + bhn;
+                    const float nn = tanhf_(ani[i][j][e] + deg * bcn + xt[2 * H + col] + rr * ghn);
+                    const float hp = (float)hin_hi[row * LDP + col] + (float)hin_lo[row * LDP + col];
+                    s_pre[row * S::LD + col] = (1.0f - zz) * nn + zz * hp;
+                    ar[i][j][e] = rr; az[i][j][e] = zz; ani[i][j][e] = nn; anh[i][j][e] = ghn;
+                }
+            }
+        idx_commit(ib[b ^ 1].idx, ri);
+        STAMP(3);
+        __syncthreads();
+        STAMP(4);
+        // ---- C. LayerNorm row statistics
+        if (has_ln) {
+            for (int row = grp; row < kTileRows; row += S::GROUPS) {
+                float4 v = ld4(s_pre + row * S::LD + 4 * lr);
+                const float mean = group_sum<S::LPR>(v.x + v.y + v.z + v.w) * (1.0f / H);
+                v = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
+                const float var = group_sum<S::LPR>(dot4(v, v)) * (1.0f / H);
+                const float rstd = rsqrtf(var + a.eps);
+                const float4 dy = ld4(s_dy + row * S::LD + 4 * lr);
+                const float4 gm = ld4(sv.lnw + 4 * lr);
+                const float4 g = make_float4(dy.x * gm.x, dy.y * gm.y, dy.z * gm.z, dy.w * gm.w);
+                const float c1 = group_sum<S::LPR>(g.x + g.y + g.z + g.w) * (1.0f / H);
+                const float c2 = group_sum<S::LPR>(dot4(g, v)) * rstd * (1.0f / H);
+                if (lr == 0) { s_stat[row * 4 + 0] = mean; s_stat[row * 4 + 1] = rstd; s_stat[row * 4 + 2] = c1; s_stat[row * 4 + 3] = c2; }
+            }
+            __syncthreads();
+        }
+        STAMP(5);
+        // ---- D. LayerNorm + GRU backward in accumulator layout
+        f32x4 dhd[S::RTW][S::HCW];
+#pragma unroll
+        for (int j = 0; j < S::HCW; ++j) {
+            const int col = (wc * S::HCW + j) * 16 + r;
+            const float gamma = sv.lnw[col];
+            float s_lw = 0.f, s_lb = 0.f, sb_r = 0.f, sb_z = 0.f, sb_nh = 0.f, sd_r = 0.f, sd_z = 0.f, sd_n = 0.f;
+#pragma unroll
+            for (int i = 0; i < S::RTW; ++i) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
+                    const float dy = s_dy[row * S::LD + col];
+                    float dh;
+                    if (has_ln) {
+                        const float mean = s_stat[row * 4 + 0], rstd = s_stat[row * 4 + 1];
+                        const float xhat = (s_pre[row * S::LD + col] - mean) * rstd;
+                        s_lw += dy * xhat; s_lb += dy;
+                        dh = rstd * (dy * gamma - s_stat[row * 4 + 2] - xhat * s_stat[row * 4 + 3]);
+                    } else {
+                        dh = dy;
+                    }
+                    const float rr = ar[i][j][e], zz = az[i][j][e], nn = ani[i][j][e], ghn = anh[i][j][e];
+                    const float hp = (float)hin_hi[row * LDP + col] + (float)hin_lo[row * LDP + col];
+                    const float dan = dh * (1.0f - zz) * (1.0f - nn * nn);
+                    const float daz = dh * (hp - nn) * zz * (1.0f - zz);
+                    const float dar = dan * ghn * rr * (1.0f - rr);
+                    const float danr = dan * rr;
+                    ar[i][j][e] = dar; az[i][j][e] = daz; ani[i][j][e] = dan; anh[i][j][e] = danr;
+                    dhd[i][j][e] = dh * zz;
+                    const float deg = sv.deg[row];
+                    sb_r += dar; sb_z += daz; sb_nh += danr;
+                    sd_r += deg * dar; sd_z += deg * daz; sd_n += deg * dan;
+                }
+            }
+            if (has_ln) { colsum_lds_x3(s_lw, s_dlnw + col); colsum_lds_x3(s_lb, s_dlnb + col); }
+            colsum_lds_x3(sb_r, s_dbhh + col); colsum_lds_x3(sb_z, s_dbhh + H + col); colsum_lds_x3(sb_nh, s_dbhh + 2 * H + col);
+            colsum_lds_x3(sd_r, s_dbc + col); colsum_lds_x3(sd_z, s_dbc + H + col); colsum_lds_x3(sd_n, s_dbc + 2 * H + col);
+            for (int c = 0; c < a.C; ++c) {
+                float tr = 0.f, tz = 0.f, tn = 0.f;
+#pragma unroll
+                for (int i = 0; i < S::RTW; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
+                        const bool m = sv.cls[row] == c;
+                        tr += m ? ar[i][j][e] : 0.f; tz += m ? az[i][j][e] : 0.f; tn += m ? ani[i][j][e] : 0.f;
+                    }
+                colsum_lds_x3(tr, s_dxt + c * 3 * H + col);
+                colsum_lds_x3(tz, s_dxt + c * 3 * H + H + col);
+                colsum_lds_x3(tn, s_dxt + c * 3 * H + 2 * H + col);
+            }
+        }
+        STAMP(6);
+        // ---- E. four gate-gradient tiles through region C (which held pre/dy until here)
+        f32x4 dag[S::RTW][S::HCW];
+#pragma unroll
+        for (int i = 0; i < S::RTW; ++i)
+#pragma unroll
+            for (int j = 0; j < S::HCW; ++j) dag[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            __syncthreads();          // readers of region C: phase D, or the previous pass
+            STAMP(14);
+#pragma unroll
+            for (int i = 0; i < S::RTW; ++i)
+#pragma unroll
+                for (int j = 0; j < S::HCW; ++j) {
+                    const int col = (wc * S::HCW + j) * 16 + r;
+                    const f32x4 v = p == 0 ? ar[i][j] : p == 1 ? az[i][j] : p == 2 ? ani[i][j] : anh[i][j];
+                    __bf16 h[4], l[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        split_bf16(v[e], h[e], l[e]);
+                        const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
+                        d_hi[row * LDP + col] = h[e];
+                        d_lo[row * LDP + col] = l[e];
+                    }
+                    // transposed copy: this lane's 4 consecutive rows of column `col` are contiguous
+                    const int row0 = (wr * S::RTW + i) * 16 + q * 4;
+                    st_bf4(dT_hi + col * LDT + row0, bf16x4{h[0], h[1], h[2], h[3]});
+                    st_bf4(dT_lo + col * LDT + row0, bf16x4{l[0], l[1], l[2], l[3]});
+                }
+            STAMP(10);
+            __syncthreads();
+            STAMP(11);
+            const int g = p < 2 ? p : 2;
+            if (need_dgrad) {
+#pragma unroll 1
+                for (int ks = 0; ks < H / 32; ++ks) {
+                    const int ko = 32 * ks + 8 * q;
+                    bf16x8 xh[S::RTW], xl[S::RTW];
+#pragma unroll
+                    for (int i = 0; i < S::RTW; ++i) {
+                        const int off = ((wr * S::RTW + i) * 16 + r) * LDP + ko;
+                        xh[i] = ldfrag(d_hi + off); xl[i] = ldfrag(d_lo + off);
+                    }
+#pragma unroll
+                    for (int j = 0; j < S::HCW; ++j) {
+                        const int col = (wc * S::HCW + j) * 16 + r;
+                        const int64_t wo = (int64_t)col * 3 * H + g * H + ko;
+                        if (p != 3) {
+                            const bf16x8 bh = ldfrag(a.wpack + 4 * BLK + wo), bl = ldfrag(a.wpack + 5 * BLK + wo);
+#pragma unroll
+                            for (int i = 0; i < S::RTW; ++i) mma_x3(dag[i][j], xh[i], xl[i], bh, bl);
+                        }
+                        if (p != 2) {
+                            const bf16x8 bh = ldfrag(a.wpack + 6 * BLK + wo), bl = ldfrag(a.wpack + 7 * BLK + wo);
+#pragma unroll
+                            for (int i = 0; i < S::RTW; ++i) mma_x3(dhd[i][j], xh[i], xl[i], bh, bl);
+                        }
+                    }
+                }
+            }
+            STAMP(12);
+            if (p != 3) wgrad_x3<H>(gWc[g], dT_hi, dT_lo, aggT_hi, aggT_lo);
+            if (p != 2) wgrad_x3<H>(gWhh[g], dT_hi, dT_lo, hinT_hi, hinT_lo);
+            STAMP(13);
+        }
+        STAMP(7);
+        // ---- F. outputs through LDS (region C as two fp32 tiles again)
+        __syncthreads();
+        STAMP(8);
+        if (need_dgrad) {
+#pragma unroll
+            for (int i = 0; i < S::RTW; ++i)
+#pragma unroll
+                for (int j = 0; j < S::HCW; ++j) {
+                    const int col = (wc * S::HCW + j) * 16 + r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
+                        s_pre[row * S::LD + col] = dag[i][j][e];
+                        s_dy[row * S::LD + col] = dhd[i][j][e];
+                    }
+                }
+            __syncthreads();
+            for (int row = grp; row < kTileRows; row += S::GROUPS) {
+                const int64_t node = base + row;
+                if (node < a.N) {
+                    st4(a.g_agg_out + node * H + 4 * lr, ld4(s_pre + row * S::LD + 4 * lr));
+                    st4(a.g_direct_out + node * H + 4 * lr, ld4(s_dy + row * S::LD + 4 * lr));
+                }
+            }
+        }
+        __syncthreads();
+        STAMP(9);
+    }
+    STAMP_FLUSH(a);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+        wgrad_flush_x3<H>(gWc[g], a.dWc + (int64_t)g * H * H);
+        wgrad_flush_x3<H>(gWhh[g], a.dWhh + (int64_t)g * H * H);
+    }
+    __syncthreads();
+    for (int i = tid; i < 3 * H; i += kThreadsX3) { atomicAdd(a.dbc + i, s_dbc[i]); atomicAdd(a.dbhh + i, s_dbhh[i]); }
+    for (int i = tid; i < a.C * 3 * H; i += kThreadsX3) atomicAdd(a.dxtab + i, s_dxt[i]);
+    if (has_ln)
+        for (int i = tid; i < H; i += kThreadsX3) { atomicAdd(a.dlnw + i, s_dlnw[i]); atomicAdd(a.dlnb + i, s_dlnb[i]); }
+}
+
+template <int H>
+int launch_fwd_x3(const StageX3Args& a, hipStream_t st) {
+    const size_t shm = X3Smem<H>::fwd_bytes;
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_struct_stage_fwd_x3<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+    int per_cu = (int)(160 * 1024 / shm);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    hipLaunchKernelGGL(k_struct_stage_fwd_x3<H>, dim3(grid_for(ntiles, per_cu)), dim3(kThreadsX3), shm, st, a);
+    MGV_LAUNCH_RET();
+}
+template <int H>
+int launch_bwd_x3(const StageX3Args& a, hipStream_t st) {
+    const size_t shm = X3Smem<H>::bwd_bytes;
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_struct_stage_bwd_x3<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+    hipLaunchKernelGGL(k_struct_stage_bwd_x3<H>, dim3(grid_for(ntiles, 1)), dim3(kThreadsX3), shm, st, a);
+    MGV_LAUNCH_RET();
+}
+
+}  // namespace mgv
+
+#ifdef MGV_STAMPS
+static unsigned long long* g_stamps = nullptr;
+extern "C" int mgv_diag_set_stamps(void* p) { g_stamps = static_cast<unsigned long long*>(p); return 0; }
+#define MGV_SET_STAMPS(a) (a).stamps = g_stamps
+#else
+#define MGV_SET_STAMPS(a)
+#endif
+
+extern "C" int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
+                                       const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
+                                       const float* bhh, const float* ln_w, const float* ln_b, float ln_eps, float* h_out,
+                                       void* stream) {
+    MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && h_out);
+    MGV_CHECK_ARG(C >= 1 && C <= mgv::kMaxClsX3);
+    MGV_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr));
+    if (N == 0) return MGV_OK;
+    MGV_CHECK_ARG(nbr_idx != nullptr);
+    mgv::StageX3Args a{};
+    a.N = N; a.h_in = h_in; a.ptr = nbr_ptr; a.idx = nbr_idx; a.xcls = xcls; a.xtab = xtab; a.C = C;
+    a.wpack = static_cast<const __bf16*>(wpack_bf16); a.bc = bc; a.bhh = bhh; a.lnw = ln_w; a.lnb = ln_b; a.eps = ln_eps; a.h_out = h_out;
+    MGV_SET_STAMPS(a);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (H) {
+        case 32: return mgv::launch_fwd_x3<32>(a, st);
+        case 64: return mgv::launch_fwd_x3<64>(a, st);
+        default: return MGV_EUNSUPPORTED;
+    }
+}
+
+extern "C" int mgv_struct_stage_bwd_x3(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
+                                       const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
+                                       const float* bhh, const float* ln_w, const float* ln_b, float ln_eps,
+                                       const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
+                                       float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
+                                       float* dln_b, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && gy_direct);
+    MGV_CHECK_ARG(dWc && dbc && dWhh && dbhh && dxtab);
+    MGV_CHECK_ARG(C >= 1 && C <= mgv::kMaxClsX3);
+    MGV_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr));
+    MGV_CHECK_ARG(ln_w == nullptr || (dln_w && dln_b));
+    MGV_CHECK_ARG((g_direct_out == nullptr) == (g_agg_out == nullptr));
+    if (N == 0) return MGV_OK;
+    MGV_CHECK_ARG(nbr_idx != nullptr);
+    mgv::StageX3Args a{};
+    a.N = N; a.h_in = h_in; a.ptr = nbr_ptr; a.idx = nbr_idx; a.xcls = xcls; a.xtab = xtab; a.C = C;
+    a.wpack = static_cast<const __bf16*>(wpack_bf16); a.bc = bc; a.bhh = bhh; a.lnw = ln_w; a.lnb = ln_b; a.eps = ln_eps;
+    a.gy_direct = gy_direct; a.gy_agg = gy_agg; a.g_direct_out = g_direct_out; a.g_agg_out = g_agg_out;
+    a.dWc = dWc; a.dbc = dbc; a.dWhh = dWhh; a.dbhh = dbhh; a.dxtab = dxtab; a.dlnw = dln_w; a.dlnb = dln_b;
+    MGV_SET_STAMPS(a);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (H) {
+        case 32: return mgv::launch_bwd_x3<32>(a, st);
+        case 64: return mgv::launch_bwd_x3<64>(a, st);
+        default: return MGV_EUNSUPPORTED;
+    }
+}

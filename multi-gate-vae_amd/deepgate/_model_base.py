@@ -62,11 +62,15 @@ class FunctionalModel(nn.Module):
     def pred_prob(self, hf, seed=None):
         return self.readout_prob(hf, clamp01=True, seed=seed)
 
-    def recon_loss(self, hs, pos_edge_index, neg_edge_index=None, want_pred=True, edge_keys=None):
+    def recon_loss(self, hs, pos_edge_index, neg_edge_index=None, want_pred=True, edge_keys=None, plan=None):
+        """`plan` (optional): the batch's GraphPlan when pos_edge_index is the batch's own edge set (any
+        order) — the positive half of the backward then needs no atomics."""
         st = ops.linear(hs, self.hs_decompose.weight, self.hs_decompose.bias)
         if neg_edge_index is None:
             neg_edge_index = negative_sampling(pos_edge_index, hs.shape[0], keys=edge_keys)
-        loss, counts, pred_bin = ops.ReconLossFn.apply(st, pos_edge_index, neg_edge_index, want_pred)
+        if plan is not None and (plan.E != pos_edge_index.shape[1] or plan.N != hs.shape[0]):
+            plan = None
+        loss, counts, pred_bin = ops.ReconLossFn.apply(st, pos_edge_index, neg_edge_index, want_pred, plan)
         self.last_confusion = counts        # {TP, FP, TN, FN} on device, no host copy needed for metrics
         Ep, En = pos_edge_index.shape[1], neg_edge_index.shape[1]
         gt_bin = None

@@ -8,10 +8,36 @@ import torch
 from . import _hip
 from ._hip import check, ptr
 
+import os
+
 F32 = torch.float32
 I32 = torch.int32
 U8 = torch.uint8
 LN_EPS = 1e-5
+
+# Arithmetic of the dense products: 'x3' = bf16x3 split-precision MFMA (hi/lo bf16 planes, three
+# products, fp32 accumulation; ~1e-5 relative per product, 3/16 of the fp32-MFMA cost), 'f32' = exact
+# fp32 MFMA.  Hidden widths the x3 kernels do not cover (H=16) always run in fp32.
+PRECISION = os.environ.get('MGV_PRECISION', 'x3')
+
+
+def use_x3(H):
+    return PRECISION == 'x3' and H in (32, 64)
+
+
+def split_bf16(w):
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+    return hi, lo
+
+
+def stage_wpack(Wc, Whh):
+    """bf16 weight pack of mgv_struct_stage_*_x3: [Wc_hi, Wc_lo, Whh_hi, Whh_lo, WcT_hi, WcT_lo, WhhT_hi, WhhT_lo]."""
+    parts = []
+    for w in (Wc, Whh, Wc.t().contiguous(), Whh.t().contiguous()):
+        hi, lo = split_bf16(w)
+        parts += [hi.reshape(-1), lo.reshape(-1)]
+    return torch.cat(parts).contiguous()
 
 
 def _zeros_like_params(*ts):
@@ -21,7 +47,7 @@ def _zeros_like_params(*ts):
 # ------------------------------------------------------------------------------------------------
 # structural encoder half round (digae_layer.py:267-275)
 # ------------------------------------------------------------------------------------------------
-def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, out=None):
+def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, out=None, wpack=None):
     N, H = h_in.shape
     check(h_in, F32, 'h_in'); check(nbr_ptr, I32, 'nbr_ptr'); check(nbr_idx, I32, 'nbr_idx'); check(xcls, U8, 'xcls')
     for n, t in (('xtab', xtab), ('Wc', Wc), ('bc', bc), ('Whh', Whh), ('bhh', bhh)):
@@ -30,16 +56,30 @@ def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
     assert nbr_ptr.numel() == N + 1 and xcls.numel() == N
     assert Wc.shape == (3 * H, H) and Whh.shape == (3 * H, H) and xtab.shape[1] == 3 * H
     h_out = torch.empty_like(h_in) if out is None else out
+    if use_x3(H):
+        wpack = stage_wpack(Wc, Whh) if wpack is None else wpack
+        _hip.call('mgv_struct_stage_fwd_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
+                  xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(h_out))
+        return h_out
     _hip.call('mgv_struct_stage_fwd', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
               xtab.shape[0], ptr(Wc), ptr(bc), ptr(Whh), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(h_out))
     return h_out
 
 
 def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, gy_direct, gy_agg,
-                     grads, need_input_grad=True):
+                     grads, need_input_grad=True, wpack=None):
     """`grads` = dict of fp32 accumulators (dWc, dbc, dWhh, dbhh, dxtab, dln_w, dln_b), added to."""
     N, H = h_in.shape
     check(gy_direct, F32, 'gy_direct'); check(gy_agg, F32, 'gy_agg')
+    if use_x3(H):
+        g_direct = torch.empty_like(h_in) if need_input_grad else None
+        g_agg = torch.empty_like(h_in) if need_input_grad else None
+        wpack = stage_wpack(Wc, Whh) if wpack is None else wpack
+        _hip.call('mgv_struct_stage_bwd_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
+                  xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(gy_direct),
+                  ptr(gy_agg), ptr(g_direct), ptr(g_agg), ptr(grads['dWc']), ptr(grads['dbc']), ptr(grads['dWhh']),
+                  ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')))
+        return g_direct, g_agg
     WcT = Wc.t().contiguous()
     WhhT = Whh.t().contiguous()
     g_direct = torch.empty_like(h_in) if need_input_grad else None
@@ -70,14 +110,15 @@ class StructEncoderFn(torch.autograd.Function):
         lw = ln_w.detach().contiguous() if ln_w is not None else None
         lb = ln_b.detach().contiguous() if ln_b is not None else None
         h = torch.ones(N, H, dtype=F32, device=dev)          # node_state = ones (digae_layer.py:260)
+        packs = (stage_wpack(par[1], par[3]), stage_wpack(par[6], par[8])) if use_x3(H) else (None, None)
         states = []
         for _ in range(rounds):
             for rev in (False, True):
                 p, i = plan.csr(rev)
                 w = par[5:] if rev else par[:5]
                 states.append(h)
-                h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb)
-        ctx.plan, ctx.xcls, ctx.rounds = plan, xcls, rounds
+                h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)])
+        ctx.plan, ctx.xcls, ctx.rounds, ctx.packs = plan, xcls, rounds, packs
         ctx.par, ctx.lw, ctx.lb, ctx.states = par, lw, lb, states
         return h
 
@@ -100,7 +141,7 @@ class StructEncoderFn(torch.autograd.Function):
                 g = dict(acc['r' if rev else 'f'])
                 g['dln_w'], g['dln_b'] = dlw, dlb
                 g_direct, g_agg = struct_stage_bwd(ctx.states[k], p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb,
-                                                   g_direct, g_agg, g, need_input_grad=(k > 0))
+                                                   g_direct, g_agg, g, need_input_grad=(k > 0), wpack=ctx.packs[int(rev)])
                 k -= 1
         ctx.states = None
         f, r = acc['f'], acc['r']
@@ -296,7 +337,8 @@ class ReconLossFn(torch.autograd.Function):
     on request, pred_bin."""
 
     @staticmethod
-    def forward(ctx, st, pos_edge_index, neg_edge_index, want_pred):
+    def forward(ctx, st, pos_edge_index, neg_edge_index, want_pred, plan=None):
+        """`plan`: GraphPlan whose edges are exactly pos_edge_index (any order) -> atomic-free positive half."""
         std = check(st.detach().contiguous(), F32, 'st')
         N, H2 = std.shape
         H = H2 // 2
@@ -312,6 +354,7 @@ class ReconLossFn(torch.autograd.Function):
                   ptr(sums), ptr(counts), ptr(pred))
         loss = (sums[0] / max(Ep, 1) + sums[1] / max(En, 1)).to(F32)
         ctx.save_for_backward(std, ps, pd, ns, nd)
+        ctx.plan = plan
         ctx.mark_non_differentiable(counts)
         if pred is not None:
             ctx.mark_non_differentiable(pred)
@@ -325,9 +368,11 @@ class ReconLossFn(torch.autograd.Function):
         H = H2 // 2
         dst_ = torch.zeros_like(std)
         g = gloss.detach().to(F32).reshape(1).contiguous()
-        _hip.call('mgv_recon_loss_bwd', H, ptr(std), ptr(std[:, H:]), H2, ptr(ps), ptr(pd), ps.numel(), ptr(ns), ptr(nd),
-                  ns.numel(), ptr(g), ptr(dst_), ptr(dst_[:, H:]))
-        return dst_, None, None, None
+        pl = ctx.plan
+        csr = (pl.out_ptr, pl.out_dst, pl.in_ptr, pl.in_src) if pl is not None else (None, None, None, None)
+        _hip.call('mgv_recon_loss_bwd', H, std.shape[0], ptr(std), ptr(std[:, H:]), H2, ptr(ps), ptr(pd), ps.numel(),
+                  *[ptr(c) for c in csr], ptr(ns), ptr(nd), ns.numel(), ptr(g), ptr(dst_), ptr(dst_[:, H:]))
+        return dst_, None, None, None, None
 
 
 def confusion_counts(pred_bin, gt_bin):

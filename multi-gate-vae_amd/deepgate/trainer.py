@@ -150,7 +150,8 @@ class Trainer():
             keys = getattr(batch, '_mgv_edge_keys', None)
             if keys is None:
                 keys = batch._mgv_edge_keys = sorted_edge_keys(batch.edge_index, batch.num_nodes)
-        loss, pred_bin, gt_bin = self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred, edge_keys=keys)
+        loss, pred_bin, gt_bin = self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred, edge_keys=keys,
+                                                       plan=getattr(batch, '_mgv_plan', None))
         loss_status = {'recon_loss': loss, 'pred_bin': pred_bin, 'gt_bin': gt_bin}
         if 'VAE' in getattr(self.args, 'model', '') and hasattr(self.model, 'kl_loss'):
             s_kl, t_kl = self.model.kl_loss()
