@@ -38,17 +38,34 @@ __device__ __forceinline__ void mma_kblock(f32x4& acc, const float4& a, const fl
     acc = mfma16(a.w, b.w, acc);
 }
 
+// Cross-lane reductions.  hipcc lowers __shfl_xor to ds_bpermute_b32 (an LDS-pipe round trip per step);
+// inside a 16-lane row the same butterfly is four v_add_f32_dpp: quad_perm [1,0,3,2], quad_perm [2,3,0,1],
+// row_half_mirror, row_mirror (after the quad steps every lane of a quad holds the quad's sum, so the
+// mirrors pair complementary quads / halves).  Only the 32- and 64-wide tails go through bpermute.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 // sum over the `width` (power of two <= 64) consecutive lanes a lane's group consists of
 template <int WIDTH>
 __device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-    for (int m = WIDTH / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if (WIDTH >= 2) v += dpp_mov<0xB1>(v);
+    if (WIDTH >= 4) v += dpp_mov<0x4E>(v);
+    if (WIDTH >= 8) v += dpp_mov<0x141>(v);
+    if (WIDTH >= 16) v += dpp_mov<0x140>(v);
+    if (WIDTH >= 32) v += __shfl_xor(v, 16, 64);
+    if (WIDTH >= 64) v += __shfl_xor(v, 32, 64);
     return v;
 }
 template <int WIDTH>
 __device__ __forceinline__ float group_max(float v) {
-#pragma unroll
-    for (int m = WIDTH / 2; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    if (WIDTH >= 2) v = fmaxf(v, dpp_mov<0xB1>(v));
+    if (WIDTH >= 4) v = fmaxf(v, dpp_mov<0x4E>(v));
+    if (WIDTH >= 8) v = fmaxf(v, dpp_mov<0x141>(v));
+    if (WIDTH >= 16) v = fmaxf(v, dpp_mov<0x140>(v));
+    if (WIDTH >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if (WIDTH >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
 

@@ -150,7 +150,10 @@ __global__ __launch_bounds__(kThreads) void k_head(int64_t N, int C, const float
         if (ok) a = ld4(A + i * C + 4 * lr);
         float y = dot4(a, wv);
         // the C/4 lanes of one row are consecutive lanes of a wave (C/4 is a power of two <= 16)
-        for (int m = cq / 2; m >= 1; m >>= 1) y += __shfl_xor(y, m, 64);
+        if (cq >= 2) y += dpp_mov<0xB1>(y);
+        if (cq >= 4) y += dpp_mov<0x4E>(y);
+        if (cq >= 8) y += dpp_mov<0x141>(y);
+        if (cq >= 16) y += dpp_mov<0x140>(y);
         y += bias;
         if (!ok) continue;
         if (!BWD) {

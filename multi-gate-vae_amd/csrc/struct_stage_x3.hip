@@ -52,8 +52,7 @@ constexpr int LDT = kTileRows + 8;      // transposed planes: [H][64 tile rows (
 constexpr int kNW = 8;                  // waves per workgroup (two per SIMD)
 constexpr int kThreadsX3 = kNW * 64;
 constexpr int kIdxCap = 1024;           // neighbour entries of one tile kept in LDS; the tail is read from global
-constexpr int kIdxRegs = kIdxCap / kThreadsX3;
-constexpr int kPtrPad = 80;             // 65 CSR pointers of a tile, padded
+constexpr int kPtrPad = 80;             // 65 CSR pointers of a tile + the tile's maximum degree at [72], padded
 
 // 8 waves over a (64 rows) x (H hidden columns) output: across column tiles first, then row tiles
 template <int H>
@@ -83,7 +82,7 @@ struct X3Smem {
     static constexpr int f_pre = f_planes;                    // fp32 pre-LayerNorm rows: reuse the agg planes once the MFMAs are done
     static_assert(F32TILE <= 2 * PB, "pre-LN tile must fit the two agg planes");
     static constexpr int f_small = f_hin + F32TILE;
-    static constexpr int IDX_BYTES = 2 * (kPtrPad + kIdxCap) * 4;
+    static constexpr int IDX_BYTES = 2 * (kPtrPad + kIdxCap + 8) * 4;
     static constexpr int f_idx = f_small + SMALL_F * 4;
     static constexpr int fwd_bytes = f_idx + IDX_BYTES;
     // backward
@@ -96,7 +95,8 @@ struct X3Smem {
     static constexpr int b_acc = b_stat + 4 * kTileRows * 4;  // dxt[C*3H], dbc[3H], dbhh[3H], dlnw[H], dlnb[H]
     static constexpr int ACC_F = kMaxClsX3 * 3 * H + 3 * H + 3 * H + H + H;
     static constexpr int b_idx = b_acc + ACC_F * 4;
-    static constexpr int bwd_bytes = b_idx + IDX_BYTES;
+    static constexpr int b_xe = b_idx + IDX_BYTES;                 // XeT_hi, XeT_lo: [16][LDT] rows = deg, onehot(cls) x8, 1, 0...
+    static constexpr int bwd_bytes = b_xe + 2 * 16 * LDT * 2;
     static_assert(bwd_bytes <= 160 * 1024, "backward LDS budget");
 };
 
@@ -115,9 +115,10 @@ __device__ __forceinline__ SmallVecs stage_small(const StageX3Args& a, float* ba
     float* deg = lnb + H;
     int* cls = reinterpret_cast<int*>(deg + kTileRows);
     const int tid = threadIdx.x;
-    for (int i = tid; i < a.C * 3 * H; i += kThreadsX3) xtab[i] = a.xtab[i];
-    for (int i = tid; i < 3 * H; i += kThreadsX3) { bc[i] = a.bc[i]; bhh[i] = a.bhh[i]; }
-    for (int i = tid; i < H; i += kThreadsX3) { lnw[i] = a.lnw ? a.lnw[i] : 1.0f; lnb[i] = a.lnb ? a.lnb[i] : 0.0f; }
+    const int nt = blockDim.x;
+    for (int i = tid; i < a.C * 3 * H; i += nt) xtab[i] = a.xtab[i];
+    for (int i = tid; i < 3 * H; i += nt) { bc[i] = a.bc[i]; bhh[i] = a.bhh[i]; }
+    for (int i = tid; i < H; i += nt) { lnw[i] = a.lnw ? a.lnw[i] : 1.0f; lnb[i] = a.lnb ? a.lnb[i] : 0.0f; }
     v.xtab = xtab; v.bc = bc; v.bhh = bhh; v.lnw = lnw; v.lnb = lnb; v.deg = deg; v.cls = cls;
     return v;
 }
@@ -127,7 +128,7 @@ __device__ __forceinline__ SmallVecs stage_small(const StageX3Args& a, float* ba
 // the CSR pointers and indices of tile t+1 are fetched while tile t is being computed and parked in LDS;
 // the row phase of a tile then consists of independent loads only (own rows + up to 4 neighbour rows
 // per lane group in flight at once).
-struct IdxLds { int* ptr; int* idx; };   // one of two LDS buffers
+struct IdxLds { int* ptr; int* idx; __device__ int* dmax() const { return ptr + 72; } };   // one of two LDS buffers
 
 __device__ __forceinline__ int ptr_prefetch(const StageX3Args& a, int64_t tile, int64_t ntiles) {
     if (tile >= ntiles || threadIdx.x > kTileRows) return 0;
@@ -136,29 +137,114 @@ __device__ __forceinline__ int ptr_prefetch(const StageX3Args& a, int64_t tile, 
     return a.ptr[n];
 }
 
-__device__ __forceinline__ void idx_prefetch(const StageX3Args& a, const int* s_ptr, int (&ri)[kIdxRegs]) {
+template <int NT>
+__device__ __forceinline__ void idx_prefetch(const StageX3Args& a, const int* s_ptr, int (&ri)[kIdxCap / NT]) {
     const int e0 = s_ptr[0], ne = s_ptr[kTileRows] - e0;
 #pragma unroll
-    for (int k = 0; k < kIdxRegs; ++k) {
-        const int i = threadIdx.x + k * kThreadsX3;
+    for (int k = 0; k < kIdxCap / NT; ++k) {
+        const int i = threadIdx.x + k * NT;
         ri[k] = i < ne ? a.idx[e0 + i] : 0;
     }
 }
 
-__device__ __forceinline__ void idx_commit(int* s_idx, const int (&ri)[kIdxRegs]) {
+template <int NT>
+__device__ __forceinline__ void idx_commit(int* s_idx, const int (&ri)[kIdxCap / NT]) {
 #pragma unroll
-    for (int k = 0; k < kIdxRegs; ++k) s_idx[threadIdx.x + k * kThreadsX3] = ri[k];
+    for (int k = 0; k < kIdxCap / NT; ++k) s_idx[threadIdx.x + k * NT] = ri[k];
 }
 
-__device__ __forceinline__ int idx_at(const StageX3Args& a, const int* s_ptr, const int* s_idx, int e) {
-    const int rel = e - s_ptr[0];
-    return rel < kIdxCap ? s_idx[rel] : a.idx[e];
+// maximum neighbour count of a tile's rows, from the CSR pointers parked in LDS (executed by wave 0)
+__device__ __forceinline__ void tile_dmax(const int* s_ptr, int* s_dmax) {
+    if (threadIdx.x < 64) {
+        int d = s_ptr[threadIdx.x + 1] - s_ptr[threadIdx.x];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) d = max(d, __shfl_xor(d, m, 64));
+        const int ne = s_ptr[kTileRows] - s_ptr[0];
+        if (threadIdx.x == 0) *s_dmax = ne > kIdxCap - 8 ? (1 << 30) : d;    // index list does not fit LDS: generic path
+    }
 }
 
-// all row loads of one tile row: own row (+ incoming gradient), neighbour sums of h_in (+ of gy_agg)
+// Row loads of RPG tile rows per lane group: own rows first, then the neighbour lists in chunks of D
+// slots per row.  Within a chunk every index is read from LDS unconditionally and every row load is
+// only predicated (no waits, no dummy traffic), so RPG*D row loads (x2 with DY) are in flight per lane.
+// The chunk loop's trip count is the tile's maximum degree: workgroup-uniform.
+template <int H, int D, int RPG, bool DY>
+__device__ __forceinline__ void rows_chunked(const StageX3Args& a, int64_t base, int grp, int groups, int lr, const int* s_ptr,
+                                             const int* s_idx, int dmax, bool two, float4 (&acc)[RPG], float4 (&own)[RPG],
+                                             float4 (&dy)[RPG], float (&deg)[RPG], int (&cls)[RPG]) {
+    // caller guarantees: the whole tile lies inside [0, N) and its index list inside LDS
+    const int e0t = s_ptr[0];
+    int rel0[RPG], d[RPG];
+#pragma unroll
+    for (int rr = 0; rr < RPG; ++rr) {
+        const int row = grp + rr * groups;
+        const int p0 = s_ptr[row];
+        rel0[rr] = p0 - e0t;
+        d[rr] = s_ptr[row + 1] - p0;
+    }
+    // chunk 0 is peeled so that its row loads are issued together with the own-row loads
+    int j0[RPG][D];
+#pragma unroll
+    for (int rr = 0; rr < RPG; ++rr)
+#pragma unroll
+        for (int k = 0; k < D; ++k) j0[rr][k] = s_idx[min(rel0[rr] + k, kIdxCap + 7)];
+    f32x4 v0[RPG][D], g0[RPG][D];
+#pragma unroll
+    for (int rr = 0; rr < RPG; ++rr) {
+        const int64_t node = base + grp + rr * groups;
+        own[rr] = ld4(a.h_in + node * H + 4 * lr);
+        if (DY) dy[rr] = ld4(a.gy_direct + node * H + 4 * lr); else dy[rr] = zero4();
+        cls[rr] = a.xcls[node];
+        // predicated loads into registers that are NOT written on the untaken path (a zero-initialised
+        // destination would be a write-after-write hazard and make the compiler drain vmcnt per load)
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if (k < d[rr]) {
+                v0[rr][k] = *reinterpret_cast<const f32x4*>(a.h_in + (int64_t)j0[rr][k] * H + 4 * lr);
+                if (DY && two) g0[rr][k] = *reinterpret_cast<const f32x4*>(a.gy_agg + (int64_t)j0[rr][k] * H + 4 * lr);
+            }
+    }
+#pragma unroll
+    for (int rr = 0; rr < RPG; ++rr) {
+        deg[rr] = (float)d[rr];
+        acc[rr] = zero4();
+#pragma unroll
+        for (int k = 0; k < D; ++k)
+            if (k < d[rr]) {
+                acc[rr] = add4(acc[rr], make_float4(v0[rr][k][0], v0[rr][k][1], v0[rr][k][2], v0[rr][k][3]));
+                if (DY && two) dy[rr] = add4(dy[rr], make_float4(g0[rr][k][0], g0[rr][k][1], g0[rr][k][2], g0[rr][k][3]));
+            }
+    }
+    for (int c0 = D; c0 < dmax; c0 += D) {
+        int j[RPG][D];
+#pragma unroll
+        for (int rr = 0; rr < RPG; ++rr)
+#pragma unroll
+            for (int k = 0; k < D; ++k) j[rr][k] = s_idx[min(rel0[rr] + c0 + k, kIdxCap + 7)];
+        f32x4 v[RPG][D], g[RPG][D];
+#pragma unroll
+        for (int rr = 0; rr < RPG; ++rr)
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if (c0 + k < d[rr]) {
+                    v[rr][k] = *reinterpret_cast<const f32x4*>(a.h_in + (int64_t)j[rr][k] * H + 4 * lr);
+                    if (DY && two) g[rr][k] = *reinterpret_cast<const f32x4*>(a.gy_agg + (int64_t)j[rr][k] * H + 4 * lr);
+                }
+#pragma unroll
+        for (int rr = 0; rr < RPG; ++rr)
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if (c0 + k < d[rr]) {
+                    acc[rr] = add4(acc[rr], make_float4(v[rr][k][0], v[rr][k][1], v[rr][k][2], v[rr][k][3]));
+                    if (DY && two) dy[rr] = add4(dy[rr], make_float4(g[rr][k][0], g[rr][k][1], g[rr][k][2], g[rr][k][3]));
+                }
+    }
+}
+
+// generic degree: per-row loops (rare tiles with a high fan-out node or an index list beyond LDS)
 template <int H, bool DY>
-__device__ __forceinline__ void row_gather(const StageX3Args& a, int64_t node, int row, int lr, const int* s_ptr, const int* s_idx,
-                                           float4& acc, float4& own, float4& dy, float& deg, int& cls) {
+__device__ __forceinline__ void row_generic(const StageX3Args& a, int64_t node, int row, int lr, const int* s_ptr, bool two,
+                                            float4& acc, float4& own, float4& dy, float& deg, int& cls) {
     acc = zero4(); own = zero4(); dy = zero4(); deg = 0.f; cls = 0;
     if (node >= a.N) return;
     const int p0 = s_ptr[row], p1 = s_ptr[row + 1];
@@ -166,27 +252,27 @@ __device__ __forceinline__ void row_gather(const StageX3Args& a, int64_t node, i
     own = ld4(a.h_in + node * H + 4 * lr);
     if (DY) dy = ld4(a.gy_direct + node * H + 4 * lr);
     cls = a.xcls[node];
+    for (int e = p0; e < p1; ++e) {
+        const int64_t jj = a.idx[e];
+        acc = add4(acc, ld4(a.h_in + jj * H + 4 * lr));
+        if (DY && two) dy = add4(dy, ld4(a.gy_agg + jj * H + 4 * lr));
+    }
+}
+
+template <int H, int RPG, bool DY>
+__device__ __forceinline__ void tile_rows(const StageX3Args& a, int64_t base, int grp, int groups, int lr, const int* s_ptr,
+                                          const int* s_idx, int dmax, float4 (&acc)[RPG], float4 (&own)[RPG], float4 (&dy)[RPG],
+                                          float (&deg)[RPG], int (&cls)[RPG]) {
     const bool two = DY && a.gy_agg != nullptr;
-    for (int e = p0; e < p1; e += 4) {
-        const int d = p1 - e;
-        float4 v0 = zero4(), v1 = zero4(), v2 = zero4(), v3 = zero4();
-        float4 g0 = zero4(), g1 = zero4(), g2 = zero4(), g3 = zero4();
-        const int64_t j0 = idx_at(a, s_ptr, s_idx, e);
-        const int64_t j1 = d > 1 ? idx_at(a, s_ptr, s_idx, e + 1) : 0;
-        const int64_t j2 = d > 2 ? idx_at(a, s_ptr, s_idx, e + 2) : 0;
-        const int64_t j3 = d > 3 ? idx_at(a, s_ptr, s_idx, e + 3) : 0;
-        v0 = ld4(a.h_in + j0 * H + 4 * lr);
-        if (d > 1) v1 = ld4(a.h_in + j1 * H + 4 * lr);
-        if (d > 2) v2 = ld4(a.h_in + j2 * H + 4 * lr);
-        if (d > 3) v3 = ld4(a.h_in + j3 * H + 4 * lr);
-        if (two) {
-            g0 = ld4(a.gy_agg + j0 * H + 4 * lr);
-            if (d > 1) g1 = ld4(a.gy_agg + j1 * H + 4 * lr);
-            if (d > 2) g2 = ld4(a.gy_agg + j2 * H + 4 * lr);
-            if (d > 3) g3 = ld4(a.gy_agg + j3 * H + 4 * lr);
+    constexpr int D = (RPG >= 4 || DY) ? 2 : 4;      // RPG*D (x2 with DY) row loads in flight per lane: 8
+    if (dmax < (1 << 30) && base + kTileRows <= a.N) {
+        rows_chunked<H, D, RPG, DY>(a, base, grp, groups, lr, s_ptr, s_idx, dmax, two, acc, own, dy, deg, cls);
+    } else {                                         // partial last tile, or an index list beyond LDS
+#pragma unroll
+        for (int rr = 0; rr < RPG; ++rr) {
+            const int row = grp + rr * groups;
+            row_generic<H, DY>(a, base + row, row, lr, s_ptr, two, acc[rr], own[rr], dy[rr], deg[rr], cls[rr]);
         }
-        acc = add4(acc, add4(add4(v0, v1), add4(v2, v3)));
-        if (two) dy = add4(dy, add4(add4(g0, g1), add4(g2, g3)));
     }
 }
 
@@ -223,7 +309,8 @@ __device__ __forceinline__ void stage_gemm_x3(const __bf16* wpack, const __bf16*
             const int col = (wc * S::HCW + j) * 16 + r;
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                const int64_t wo = (int64_t)(g * H + col) * H + ko;
+                // fragment order: block (row tile, k-step) = 512 contiguous elements, lane l at 8*l
+                const int wo = ((g * (H / 16) + wc * S::HCW + j) * (H / 32) + ks) * 512 + lane * 8;
                 const bf16x8 ch = ldfrag(wpack + 0 * BLK + wo), cl = ldfrag(wpack + 1 * BLK + wo);
                 const bf16x8 uh = ldfrag(wpack + 2 * BLK + wo), ul = ldfrag(wpack + 3 * BLK + wo);
 #pragma unroll
@@ -238,11 +325,18 @@ __device__ __forceinline__ void stage_gemm_x3(const __bf16* wpack, const __bf16*
     }
 }
 
+// Forward kernel: 4 waves per workgroup, two workgroups per CU.  Every wave owns one 16-column tile of
+// the three gates for ALL its tiles, so its 2*3*(H/32) weight fragment pairs (96 VGPRs at H=64) are
+// loaded once per kernel and stay in registers: the dense phase touches LDS only.
+constexpr int kThreadsF = 256;
+
 template <int H>
-__global__ __launch_bounds__(kThreadsX3, 4) void k_struct_stage_fwd_x3(StageX3Args a) {
-    using S = SplitX3<H>;
+__global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Args a) {
+    using S = WaveSplit<H>;                 // 4 waves: column tiles first, then row tiles (mgv_common.h)
     using M = X3Smem<H>;
-    constexpr int LDP = M::LDP;
+    static_assert(S::HCW == 1, "one hidden-column tile per wave");
+    constexpr int LDP = M::LDP, BLK = 3 * H * H, KS = H / 32;
+    constexpr int RPG = kTileRows / S::GROUPS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* agg_hi = reinterpret_cast<__bf16*>(smem_raw + M::f_planes);
     __bf16* agg_lo = reinterpret_cast<__bf16*>(smem_raw + M::f_planes + M::PB);
@@ -256,15 +350,27 @@ __global__ __launch_bounds__(kThreadsX3, 4) void k_struct_stage_fwd_x3(StageX3Ar
     const int grp = tid / S::LPR, lr = tid % S::LPR;
     const bool has_ln = a.lnw != nullptr;
     const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+
+    // persistent weight fragments of this wave's column tile: [k-step][gate] x {Wc hi, Wc lo, Whh hi, Whh lo}
+    bf16x8 wch[KS][3], wcl[KS][3], wuh[KS][3], wul[KS][3];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int wo = ((g * (H / 16) + wc) * KS + ks) * 512 + lane * 8;
+            wch[ks][g] = ldfrag(a.wpack + 0 * BLK + wo); wcl[ks][g] = ldfrag(a.wpack + 1 * BLK + wo);
+            wuh[ks][g] = ldfrag(a.wpack + 2 * BLK + wo); wul[ks][g] = ldfrag(a.wpack + 3 * BLK + wo);
+        }
+
     int* idx_base = reinterpret_cast<int*>(smem_raw + M::f_idx);
-    IdxLds ib[2] = {{idx_base, idx_base + kPtrPad}, {idx_base + kPtrPad + kIdxCap, idx_base + 2 * kPtrPad + kIdxCap}};
-    // prologue: indices of this workgroup's first tile, pointers of its second
+    IdxLds ib[2] = {{idx_base, idx_base + kPtrPad}, {idx_base + kPtrPad + kIdxCap + 8, idx_base + 2 * kPtrPad + kIdxCap + 8}};
     int rp = ptr_prefetch(a, blockIdx.x, ntiles);
     if (tid <= kTileRows) ib[0].ptr[tid] = rp;
     __syncthreads();
-    int ri[kIdxRegs];
-    idx_prefetch(a, ib[0].ptr, ri);
-    idx_commit(ib[0].idx, ri);
+    int ri[kIdxCap / kThreadsF];
+    idx_prefetch<kThreadsF>(a, ib[0].ptr, ri);
+    idx_commit<kThreadsF>(ib[0].idx, ri);
+    tile_dmax(ib[0].ptr, ib[0].dmax());
     rp = ptr_prefetch(a, (int64_t)blockIdx.x + gridDim.x, ntiles);
     __syncthreads();
     int b = 0;
@@ -273,53 +379,68 @@ __global__ __launch_bounds__(kThreadsX3, 4) void k_struct_stage_fwd_x3(StageX3Ar
         const int64_t base = tile * kTileRows;
         STAMP_BEGIN;
         // ---- row phase: independent loads only
+        {
+            float4 acc[RPG], own[RPG], dy[RPG];
+            float deg[RPG];
+            int cls[RPG];
+            tile_rows<H, RPG, false>(a, base, grp, S::GROUPS, lr, ib[b].ptr, ib[b].idx, *ib[b].dmax(), acc, own, dy, deg, cls);
 #pragma unroll
-        for (int rr = 0; rr < kTileRows / S::GROUPS; ++rr) {
-            const int row = grp + rr * S::GROUPS;
-            float4 acc, own, dy;
-            float deg;
-            int cls;
-            row_gather<H, false>(a, base + row, row, lr, ib[b].ptr, ib[b].idx, acc, own, dy, deg, cls);
-            bf16x4 hi, lo;
-            split4(acc, hi, lo);
-            st_bf4(agg_hi + row * LDP + 4 * lr, hi); st_bf4(agg_lo + row * LDP + 4 * lr, lo);
-            split4(own, hi, lo);
-            st_bf4(hin_hi + row * LDP + 4 * lr, hi); st_bf4(hin_lo + row * LDP + 4 * lr, lo);
-            st4(s_hin + row * S::LD + 4 * lr, own);
-            if (lr == 0) { sv.deg[row] = deg; sv.cls[row] = cls; }
+            for (int rr = 0; rr < RPG; ++rr) {
+                const int row = grp + rr * S::GROUPS;
+                bf16x4 hi, lo;
+                split4(acc[rr], hi, lo);
+                st_bf4(agg_hi + row * LDP + 4 * lr, hi); st_bf4(agg_lo + row * LDP + 4 * lr, lo);
+                split4(own[rr], hi, lo);
+                st_bf4(hin_hi + row * LDP + 4 * lr, hi); st_bf4(hin_lo + row * LDP + 4 * lr, lo);
+                st4(s_hin + row * S::LD + 4 * lr, own[rr]);
+                if (lr == 0) { sv.deg[row] = deg[rr]; sv.cls[row] = cls[rr]; }
+            }
         }
-        if (tid <= kTileRows) ib[b ^ 1].ptr[tid] = rp;       // pointers of the next tile (loaded one tile ago)
+        if (tid <= kTileRows) ib[b ^ 1].ptr[tid] = rp;       // pointers of the next tile (requested one tile ago)
         STAMP(0);
         __syncthreads();
         STAMP(1);
-        idx_prefetch(a, ib[b ^ 1].ptr, ri);                   // in flight during the dense part
+        // next tile's indices and the tile after's pointers fly during the dense part + epilogue
+        idx_prefetch<kThreadsF>(a, ib[b ^ 1].ptr, ri);
         rp = ptr_prefetch(a, tile + 2 * (int64_t)gridDim.x, ntiles);
-        f32x4 ar[S::RTW][S::HCW], az[S::RTW][S::HCW], ani[S::RTW][S::HCW], anh[S::RTW][S::HCW];
-        stage_gemm_x3<H>(a.wpack, agg_hi, agg_lo, hin_hi, hin_lo, ar, az, ani, anh);
+        tile_dmax(ib[b ^ 1].ptr, ib[b ^ 1].dmax());
+        // ---- dense part: LDS fragments x register-resident weights
+        f32x4 ar[S::RTW], az[S::RTW], ani[S::RTW], anh[S::RTW];
+#pragma unroll
+        for (int i = 0; i < S::RTW; ++i) { ar[i] = f32x4{0.f, 0.f, 0.f, 0.f}; az[i] = ar[i]; ani[i] = ar[i]; anh[i] = ar[i]; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < S::RTW; ++i) {
+                const int off = ((wr * S::RTW + i) * 16 + r) * LDP + 32 * ks + 8 * q;
+                const bf16x8 ah = ldfrag(agg_hi + off), al = ldfrag(agg_lo + off);
+                const bf16x8 hh = ldfrag(hin_hi + off), hl = ldfrag(hin_lo + off);
+                mma_x3(ar[i], ah, al, wch[ks][0], wcl[ks][0]); mma_x3(ar[i], hh, hl, wuh[ks][0], wul[ks][0]);
+                mma_x3(az[i], ah, al, wch[ks][1], wcl[ks][1]); mma_x3(az[i], hh, hl, wuh[ks][1], wul[ks][1]);
+                mma_x3(ani[i], ah, al, wch[ks][2], wcl[ks][2]); mma_x3(anh[i], hh, hl, wuh[ks][2], wul[ks][2]);
+            }
         STAMP(2);
         __syncthreads();        // s_pre overlays the agg planes
         STAMP(3);
+        {
+            const int col = wc * 16 + r;
+            const float bcr = sv.bc[col], bcz = sv.bc[H + col], bcn = sv.bc[2 * H + col];
+            const float bhr = sv.bhh[col], bhz = sv.bhh[H + col], bhn = sv.bhh[2 * H + col];
 #pragma unroll
-        for (int i = 0; i < S::RTW; ++i)
-#pragma unroll
-            for (int j = 0; j < S::HCW; ++j) {
-                const int col = (wc * S::HCW + j) * 16 + r;
-                const float bcr = sv.bc[col], bcz = sv.bc[H + col], bcn = sv.bc[2 * H + col];
-                const float bhr = sv.bhh[col], bhz = sv.bhh[H + col], bhn = sv.bhh[2 * H + col];
+            for (int i = 0; i < S::RTW; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
                     const float deg = sv.deg[row];
                     const float* xt = sv.xtab + sv.cls[row] * 3 * H;
-                    const float rr = sigmoidf_(ar[i][j][e] + deg * bcr + xt[col] + bhr);
-                    const float zz = sigmoidf_(az[i][j][e] + deg * bcz + xt[H + col] + bhz);
-                    const float nn = tanhf_(ani[i][j][e] + deg * bcn + xt[2 * H + col] + rr * (anh[i][j][e] + bhn));
+                    const float rr = sigmoidf_(ar[i][e] + deg * bcr + xt[col] + bhr);
+                    const float zz = sigmoidf_(az[i][e] + deg * bcz + xt[H + col] + bhz);
+                    const float nn = tanhf_(ani[i][e] + deg * bcn + xt[2 * H + col] + rr * (anh[i][e] + bhn));
                     const float hp = s_hin[row * S::LD + col];
                     s_pre[row * S::LD + col] = (1.0f - zz) * nn + zz * hp;
                 }
-            }
+        }
         STAMP(4);
-        idx_commit(ib[b ^ 1].idx, ri);
         STAMP(5);
         __syncthreads();
         STAMP(6);
@@ -331,12 +452,14 @@ __global__ __launch_bounds__(kThreadsX3, 4) void k_struct_stage_fwd_x3(StageX3Ar
                 v = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
                 const float var = group_sum<S::LPR>(dot4(v, v)) * (1.0f / H);
                 const float rstd = rsqrtf(var + a.eps);
-                const float4 g = ld4(sv.lnw + 4 * lr), b = ld4(sv.lnb + 4 * lr);
-                v = make_float4(v.x * rstd * g.x + b.x, v.y * rstd * g.y + b.y, v.z * rstd * g.z + b.z, v.w * rstd * g.w + b.w);
+                const float4 g = ld4(sv.lnw + 4 * lr), bb = ld4(sv.lnb + 4 * lr);
+                v = make_float4(v.x * rstd * g.x + bb.x, v.y * rstd * g.y + bb.y, v.z * rstd * g.z + bb.z, v.w * rstd * g.w + bb.w);
             }
             if (node < a.N) st4(a.h_out + node * H + 4 * lr, v);
         }
+        idx_commit<kThreadsF>(ib[b ^ 1].idx, ri);
         STAMP(7);
+        __syncthreads();
     }
     STAMP_FLUSH(a);
 }
@@ -422,6 +545,8 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
     float* s_dbhh = s_dbc + 3 * H;
     float* s_dlnw = s_dbhh + 3 * H;
     float* s_dlnb = s_dlnw + H;
+    __bf16* xeT_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_xe);
+    __bf16* xeT_lo = xeT_hi + 16 * LDT;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
     for (int i = tid; i < M::ACC_F; i += kThreadsX3) s_dxt[i] = 0.f;
     const int wc = w % S::WPC, wr = w / S::WPC;
@@ -435,53 +560,68 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int t = 0; t < W::TPW; ++t) { gWc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f}; gWhh[g][t] = gWc[g][t]; }
+    // bias-type gradients (dbc, dxtab, dbhh) as one more wgrad tile per pass: dG^T x [deg, onehot(cls), 1]
+    f32x4 gX[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) gX[p] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
     int* idx_base = reinterpret_cast<int*>(smem_raw + M::b_idx);
-    IdxLds ib[2] = {{idx_base, idx_base + kPtrPad}, {idx_base + kPtrPad + kIdxCap, idx_base + 2 * kPtrPad + kIdxCap}};
+    IdxLds ib[2] = {{idx_base, idx_base + kPtrPad}, {idx_base + kPtrPad + kIdxCap + 8, idx_base + 2 * kPtrPad + kIdxCap + 8}};
     int rp = ptr_prefetch(a, blockIdx.x, ntiles);
     if (tid <= kTileRows) ib[0].ptr[tid] = rp;
     __syncthreads();
-    int ri[kIdxRegs];
-    idx_prefetch(a, ib[0].ptr, ri);
-    idx_commit(ib[0].idx, ri);
+    int ri[kIdxCap / kThreadsX3];
+    idx_prefetch<kThreadsX3>(a, ib[0].ptr, ri);
+    idx_commit<kThreadsX3>(ib[0].idx, ri);
+    tile_dmax(ib[0].ptr, ib[0].dmax());
     rp = ptr_prefetch(a, (int64_t)blockIdx.x + gridDim.x, ntiles);
     __syncthreads();
     int b = 0;
     STAMP_DECL
+    constexpr int RPG = kTileRows / S::GROUPS;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, b ^= 1) {
         const int64_t base = tile * kTileRows;
         STAMP_BEGIN;
         // ---- A. row phase (independent loads); operand planes row-major (GEMM A operands) and
         //        transposed (wgrad B operands)
+        {
+            float4 acc[RPG], own[RPG], dy[RPG];
+            float deg[RPG];
+            int cls[RPG];
+            tile_rows<H, RPG, true>(a, base, grp, S::GROUPS, lr, ib[b].ptr, ib[b].idx, *ib[b].dmax(), acc, own, dy, deg, cls);
 #pragma unroll
-        for (int rr = 0; rr < kTileRows / S::GROUPS; ++rr) {
-            const int row = grp + rr * S::GROUPS;
-            float4 acc, own, dy;
-            float deg;
-            int cls;
-            row_gather<H, true>(a, base + row, row, lr, ib[b].ptr, ib[b].idx, acc, own, dy, deg, cls);
-            bf16x4 hi, lo;
-            split4(acc, hi, lo);
-            st_bf4(agg_hi + row * LDP + 4 * lr, hi); st_bf4(agg_lo + row * LDP + 4 * lr, lo);
+            for (int rr = 0; rr < RPG; ++rr) {
+                const int row = grp + rr * S::GROUPS;
+                bf16x4 hi, lo;
+                split4(acc[rr], hi, lo);
+                st_bf4(agg_hi + row * LDP + 4 * lr, hi); st_bf4(agg_lo + row * LDP + 4 * lr, lo);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { aggT_hi[(4 * lr + c) * LDT + row] = hi[c]; aggT_lo[(4 * lr + c) * LDT + row] = lo[c]; }
-            split4(own, hi, lo);
-            st_bf4(hin_hi + row * LDP + 4 * lr, hi); st_bf4(hin_lo + row * LDP + 4 * lr, lo);
+                for (int c = 0; c < 4; ++c) { aggT_hi[(4 * lr + c) * LDT + row] = hi[c]; aggT_lo[(4 * lr + c) * LDT + row] = lo[c]; }
+                split4(own[rr], hi, lo);
+                st_bf4(hin_hi + row * LDP + 4 * lr, hi); st_bf4(hin_lo + row * LDP + 4 * lr, lo);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { hinT_hi[(4 * lr + c) * LDT + row] = hi[c]; hinT_lo[(4 * lr + c) * LDT + row] = lo[c]; }
-            st4(s_dy + row * S::LD + 4 * lr, dy);
-            if (lr == 0) { sv.deg[row] = deg; sv.cls[row] = cls; }
+                for (int c = 0; c < 4; ++c) { hinT_hi[(4 * lr + c) * LDT + row] = hi[c]; hinT_lo[(4 * lr + c) * LDT + row] = lo[c]; }
+                st4(s_dy + row * S::LD + 4 * lr, dy[rr]);
+                if (lr == 0) { sv.deg[row] = deg[rr]; sv.cls[row] = cls[rr]; }
+                if (lr < 16) {
+                    const float xe = lr == 0 ? deg[rr] : (lr <= 8 ? (cls[rr] == lr - 1 ? 1.0f : 0.0f) : (lr == 9 ? 1.0f : 0.0f));
+                    __bf16 xh, xl;
+                    split_bf16(xe, xh, xl);
+                    xeT_hi[lr * LDT + row] = xh; xeT_lo[lr * LDT + row] = xl;
+                }
+            }
         }
         if (tid <= kTileRows) ib[b ^ 1].ptr[tid] = rp;
         STAMP(0);
         __syncthreads();
         STAMP(1);
-        idx_prefetch(a, ib[b ^ 1].ptr, ri);
-        rp = ptr_prefetch(a, tile + 2 * (int64_t)gridDim.x, ntiles);
         // ---- B. recompute gates; keep the own-row values (hi+lo) for the GRU backward
         f32x4 ar[S::RTW][S::HCW], az[S::RTW][S::HCW], ani[S::RTW][S::HCW], anh[S::RTW][S::HCW];
         stage_gemm_x3<H>(a.wpack, agg_hi, agg_lo, hin_hi, hin_lo, ar, az, ani, anh);
+        idx_prefetch<kThreadsX3>(a, ib[b ^ 1].ptr, ri);          // after the weight fragments (vmcnt is in order); committed at the tile's end
+        rp = ptr_prefetch(a, tile + 2 * (int64_t)gridDim.x, ntiles);
+        tile_dmax(ib[b ^ 1].ptr, ib[b ^ 1].dmax());
         STAMP(2);
 #pragma unroll
         for (int i = 0; i < S::RTW; ++i)
@@ -504,7 +644,6 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                     ar[i][j][e] = rr; az[i][j][e] = zz; ani[i][j][e] = nn; anh[i][j][e] = ghn;
                 }
             }
-        idx_commit(ib[b ^ 1].idx, ri);
         STAMP(3);
         __syncthreads();
         STAMP(4);
@@ -532,7 +671,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
         for (int j = 0; j < S::HCW; ++j) {
             const int col = (wc * S::HCW + j) * 16 + r;
             const float gamma = sv.lnw[col];
-            float s_lw = 0.f, s_lb = 0.f, sb_r = 0.f, sb_z = 0.f, sb_nh = 0.f, sd_r = 0.f, sd_z = 0.f, sd_n = 0.f;
+            float s_lw = 0.f, s_lb = 0.f;
 #pragma unroll
             for (int i = 0; i < S::RTW; ++i) {
 #pragma unroll
@@ -556,28 +695,9 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                     const float danr = dan * rr;
                     ar[i][j][e] = dar; az[i][j][e] = daz; ani[i][j][e] = dan; anh[i][j][e] = danr;
                     dhd[i][j][e] = dh * zz;
-                    const float deg = sv.deg[row];
-                    sb_r += dar; sb_z += daz; sb_nh += danr;
-                    sd_r += deg * dar; sd_z += deg * daz; sd_n += deg * dan;
                 }
             }
             if (has_ln) { colsum_lds_x3(s_lw, s_dlnw + col); colsum_lds_x3(s_lb, s_dlnb + col); }
-            colsum_lds_x3(sb_r, s_dbhh + col); colsum_lds_x3(sb_z, s_dbhh + H + col); colsum_lds_x3(sb_nh, s_dbhh + 2 * H + col);
-            colsum_lds_x3(sd_r, s_dbc + col); colsum_lds_x3(sd_z, s_dbc + H + col); colsum_lds_x3(sd_n, s_dbc + 2 * H + col);
-            for (int c = 0; c < a.C; ++c) {
-                float tr = 0.f, tz = 0.f, tn = 0.f;
-#pragma unroll
-                for (int i = 0; i < S::RTW; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
-                        const bool m = sv.cls[row] == c;
-                        tr += m ? ar[i][j][e] : 0.f; tz += m ? az[i][j][e] : 0.f; tn += m ? ani[i][j][e] : 0.f;
-                    }
-                colsum_lds_x3(tr, s_dxt + c * 3 * H + col);
-                colsum_lds_x3(tz, s_dxt + c * 3 * H + H + col);
-                colsum_lds_x3(tn, s_dxt + c * 3 * H + 2 * H + col);
-            }
         }
         STAMP(6);
         // ---- E. four gate-gradient tiles through region C (which held pre/dy until here)
@@ -625,8 +745,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                     }
 #pragma unroll
                     for (int j = 0; j < S::HCW; ++j) {
-                        const int col = (wc * S::HCW + j) * 16 + r;
-                        const int64_t wo = (int64_t)col * 3 * H + g * H + ko;
+                        const int wo = (((wc * S::HCW + j) * 3 + g) * (H / 32) + ks) * 512 + lane * 8;   // fragment order
                         if (p != 3) {
                             const bf16x8 bh = ldfrag(a.wpack + 4 * BLK + wo), bl = ldfrag(a.wpack + 5 * BLK + wo);
 #pragma unroll
@@ -643,6 +762,14 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
             STAMP(12);
             if (p != 3) wgrad_x3<H>(gWc[g], dT_hi, dT_lo, aggT_hi, aggT_lo);
             if (p != 2) wgrad_x3<H>(gWhh[g], dT_hi, dT_lo, hinT_hi, hinT_lo);
+            if (w < H / 16) {          // wave-uniform: gate-column tile w of the bias-type gradients
+#pragma unroll
+                for (int ks = 0; ks < kTileRows / 32; ++ks) {
+                    const int ko = 32 * ks + 8 * q;
+                    mma_x3(gX[p], ldfrag(dT_hi + (w * 16 + r) * LDT + ko), ldfrag(dT_lo + (w * 16 + r) * LDT + ko),
+                           ldfrag(xeT_hi + r * LDT + ko), ldfrag(xeT_lo + r * LDT + ko));
+                }
+            }
             STAMP(13);
         }
         STAMP(7);
@@ -671,6 +798,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                 }
             }
         }
+        idx_commit<kThreadsX3>(ib[b ^ 1].idx, ri);
         __syncthreads();
         STAMP(9);
     }
@@ -680,9 +808,24 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
         wgrad_flush_x3<H>(gWc[g], a.dWc + (int64_t)g * H * H);
         wgrad_flush_x3<H>(gWhh[g], a.dWhh + (int64_t)g * H * H);
     }
+    if (w < H / 16) {
+        // gX[p][e] = sum_rows dG_p[row][i] * Xe[row][j] with i = 16w + 4q + e, j = r:
+        //   j = 0 -> deg-weighted (dbc), j = 1..8 -> per feature class (dxtab), j = 9 -> plain column sum (dbhh)
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = w * 16 + q * 4 + e;
+                const float v = gX[p][e];
+                const int g = p < 2 ? p : 2;
+                if (p != 3) {
+                    if (r == 0) atomicAdd(a.dbc + g * H + i, v);
+                    if (r >= 1 && r <= 8 && r - 1 < a.C) atomicAdd(a.dxtab + (r - 1) * 3 * H + g * H + i, v);
+                }
+                if (p != 2 && r == 9) atomicAdd(a.dbhh + g * H + i, v);
+            }
+    }
     __syncthreads();
-    for (int i = tid; i < 3 * H; i += kThreadsX3) { atomicAdd(a.dbc + i, s_dbc[i]); atomicAdd(a.dbhh + i, s_dbhh[i]); }
-    for (int i = tid; i < a.C * 3 * H; i += kThreadsX3) atomicAdd(a.dxtab + i, s_dxt[i]);
     if (has_ln)
         for (int i = tid; i < H; i += kThreadsX3) { atomicAdd(a.dlnw + i, s_dlnw[i]); atomicAdd(a.dlnb + i, s_dlnb[i]); }
 }
@@ -695,7 +838,7 @@ int launch_fwd_x3(const StageX3Args& a, hipStream_t st) {
     const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
     int per_cu = (int)(160 * 1024 / shm);
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
-    hipLaunchKernelGGL(k_struct_stage_fwd_x3<H>, dim3(grid_for(ntiles, per_cu)), dim3(kThreadsX3), shm, st, a);
+    hipLaunchKernelGGL(k_struct_stage_fwd_x3<H>, dim3(grid_for(ntiles, per_cu)), dim3(kThreadsF), shm, st, a);
     MGV_LAUNCH_RET();
 }
 template <int H>

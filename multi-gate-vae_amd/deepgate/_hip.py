@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _PKG_ROOT = os.path.dirname(_HERE)                      # multi-gate-vae_amd/
 _REPO_ROOT = os.path.dirname(_PKG_ROOT)
-LIB_PATH = os.path.join(_PKG_ROOT, 'csrc', 'libmgvae_hip.so')
+LIB_PATH = os.environ.get('MGV_LIB', os.path.join(_PKG_ROOT, 'csrc', 'libmgvae_hip.so'))   # MGV_LIB: A/B-test builds
 HEADER_PATH = os.path.join(_REPO_ROOT, 'include', 'mgvae_hip.h')
 
 _CTYPE = (('int64_t', ctypes.c_int64), ('uint64_t', ctypes.c_uint64), ('int32_t', ctypes.c_int32),

@@ -31,12 +31,20 @@ def split_bf16(w):
     return hi, lo
 
 
+def frag_order(w):
+    """[R, K] (k contiguous) -> MFMA 16x16x32 fragment order: blocks (row tile, k-step) of 512 elements in
+    which lane l = 16*q + r holds w[16*rt + r, 32*ks + 8*q : +8] at offset 8*l (one coalesced 1 KiB load)."""
+    R, K = w.shape
+    return w.reshape(R // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
+
+
 def stage_wpack(Wc, Whh):
-    """bf16 weight pack of mgv_struct_stage_*_x3: [Wc_hi, Wc_lo, Whh_hi, Whh_lo, WcT_hi, WcT_lo, WhhT_hi, WhhT_lo]."""
+    """bf16 weight pack of mgv_struct_stage_*_x3: [Wc_hi, Wc_lo, Whh_hi, Whh_lo, WcT_hi, WcT_lo, WhhT_hi, WhhT_lo],
+    each block in fragment order."""
     parts = []
     for w in (Wc, Whh, Wc.t().contiguous(), Whh.t().contiguous()):
         hi, lo = split_bf16(w)
-        parts += [hi.reshape(-1), lo.reshape(-1)]
+        parts += [frag_order(hi), frag_order(lo)]
     return torch.cat(parts).contiguous()
 
 

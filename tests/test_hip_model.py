@@ -25,6 +25,14 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name + '.npz'))
 
 
+def grad_atol():
+    """Gradient tolerance relative to the tensor's largest entry: 1e-4 for the exact-fp32 kernels,
+    1e-3 for the default bf16x3 split-precision kernels (~1e-5 per product, chained through 16 half
+    rounds forward and backward)."""
+    from deepgate import ops
+    return 1e-4 if ops.PRECISION == "f32" else 1e-3
+
+
 def close(a, b, rtol=2e-4, atol=2e-5, msg=''):
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
@@ -110,7 +118,7 @@ def test_train_step_losses_grads_adam_match_reference(name):
             assert float(np.abs(ref[:, :H]).max()) < 1e-5
             g, ref = g[:, H:], ref[:, H:]
         scale = max(1e-6, float(np.abs(ref).max()))
-        np.testing.assert_allclose(g, ref, rtol=1e-3, atol=1e-4 * scale + 1e-6, err_msg='grad ' + k)
+        np.testing.assert_allclose(g, ref, rtol=1e-3, atol=grad_atol() * scale + 1e-6, err_msg='grad ' + k)
     if 'after_hs_linear.weight' in z.files:
         tr.optimizer.step()
         sd = model.state_dict()
