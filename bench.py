@@ -29,7 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, fp32-input matrix peak (dense)
-PEAK_HBM_GBPS = 8000.0
+PEAK_HBM_GBPS = 8000.0           # HBM3E spec (6.3 TB/s is what a streaming copy reaches)
 
 
 def cpu_baseline(cfg, H, rounds, seed_sd, graphs=2):
@@ -83,13 +83,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit('--gpus %d needs a torchrun launch with that many ranks (WORLD_SIZE=%d)' % (a.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    local_dev = local_rank % ndev           # one rank per GPU; wraps only in single-GPU rehearsals of the N>1 path
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     if world > 1 and not dist.is_initialized():
-        dist.init_process_group(backend='nccl', init_method='env://', device_id=dev)
+        backend = os.environ.get('MGV_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; gloo only for rehearsals
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', init_method='env://', device_id=dev)
+        else:
+            dist.init_process_group(backend=backend, init_method='env://')
 
     import deepgate
-    from deepgate import _hip, synthetic as syn
+    from deepgate import _hip, ops, synthetic as syn
     from deepgate.data import plan_of
     cfg = syn.CONFIGS[a.config]
     ctype = cfg['ctype']
@@ -146,22 +152,28 @@ def main():
             print('  %-24s %6d calls %10.3f ms total %9.3f ms/call' % (name, calls, ms, ms / max(calls, 1)), file=sys.stderr)
         dom, (calls, ms) = order[0]
         per_launch_s = ms / calls * 1e-3
-        flops = {'mgv_struct_stage_bwd': 36.0 * H * H * N, 'mgv_struct_stage_fwd': 12.0 * H * H * N}.get(dom)
-        abytes = {'mgv_struct_stage_bwd': 4.0 * H * (2 * E + 4 * N) + 8.0 * (N + E),
-                  'mgv_struct_stage_fwd': 4.0 * H * (E + 2 * N) + 4.0 * (2 * N + E)}.get(dom)
-        if flops is not None:
-            ach = flops / per_launch_s / 1e12
-            roof = {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach / PEAK_F32_MFMA_TFLOPS, 'traffic': None, 'launch_ms': per_launch_s * 1e3,
-                    'algorithmic_GBps': abytes / per_launch_s / 1e9}
+        # algorithmic cost of one launch: rows gathered/streamed once, fp32 storage
+        fl = {'mgv_struct_stage_bwd': 36.0 * H * H * N, 'mgv_struct_stage_fwd': 12.0 * H * H * N,
+              'mgv_struct_stage_bwd_x3': 36.0 * H * H * N, 'mgv_struct_stage_fwd_x3': 12.0 * H * H * N}.get(dom)
+        by = {'mgv_struct_stage_bwd': 4.0 * H * (2 * E + 4 * N) + 8.0 * (N + E), 'mgv_struct_stage_fwd': 4.0 * H * (E + 2 * N) + 4.0 * (2 * N + E),
+              'mgv_struct_stage_bwd_x3': 4.0 * H * (2 * E + 4 * N) + 8.0 * (N + E),
+              'mgv_struct_stage_fwd_x3': 4.0 * H * (E + 2 * N) + 4.0 * (2 * N + E)}.get(dom)
+        roof = {'kernel': dom, 'launch_ms': per_launch_s * 1e3, 'traffic': None}
+        if dom.endswith('_x3') and by is not None:
+            ach = by / per_launch_s / 1e9          # split-precision MFMA makes the half round HBM-bound
+            roof.update(bound='hbm', achieved=ach, peak=PEAK_HBM_GBPS, unit='GB/s', frac=ach / PEAK_HBM_GBPS,
+                        algorithmic_TFLOPs=fl / per_launch_s / 1e12)
+        elif fl is not None:
+            ach = fl / per_launch_s / 1e12
+            roof.update(bound='mfma', achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=ach / PEAK_F32_MFMA_TFLOPS,
+                        algorithmic_GBps=by / per_launch_s / 1e9)
         else:
-            roof = {'kernel': dom, 'bound': 'hbm', 'achieved': None, 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s', 'frac': None,
-                    'traffic': None, 'launch_ms': per_launch_s * 1e3}
+            roof.update(bound='hbm', achieved=None, peak=PEAK_HBM_GBPS, unit='GB/s', frac=None)
         out = {
             'metric': 'circuit-graphs/sec (train step), AIG-64k batch=64 per GPU', 'value': world * B * a.steps / elapsed,
             'unit': 'graphs/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32 (dense products as bf16x3 split-precision MFMA, fp32 accumulate)' if ops.PRECISION == 'x3' else 'f32', 'data': 'synthetic',
             'nodes_per_s': world * N * a.steps / elapsed,
             'config': {'workload': 'cfg%d: DG_AE --type %s, %d x %d-node synthetic levelised DAGs per GPU (N=%d, E=%d, %d levels), '
                                    'H=64, 4+4 rounds, layernorm, weights [1,4,4], negatives %s' % (

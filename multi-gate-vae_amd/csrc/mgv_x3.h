@@ -37,6 +37,20 @@ __device__ __forceinline__ void mma_x3(f32x4& c, const bf16x8& ahi, const bf16x8
     c = mfma_bf16(ahi, bhi, c);
 }
 
+// Transposed MFMA operand fragment straight from a ROW-major bf16 plane: the 8 k-values a lane needs are 8
+// consecutive ROWS (k0 + 8q .. +7) of ONE column (c0 + r).  ds_read_b64_tr_b16 hands lane i of a 16-lane
+// group column i of a 4-row x 16-column block (lane 4q'+p supplies the address of block row q', columns
+// 4p..4p+3; checked on hardware by tools/test_tr_read.hip), so two of them make the fragment and no
+// transposed copy of the tile is ever written.  All 64 lanes must be active (the ISA requires full EXEC).
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 ldfrag_tr(const __bf16* plane, int ld, int k0, int c0) {
+    const int lane = threadIdx.x & 63, q = lane >> 4, i16 = lane & 15;
+    const __bf16* p = plane + (k0 + 8 * q + (i16 >> 2)) * ld + c0 + 4 * (i16 & 3);
+    const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4v*)p);
+    const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4v*)(p + 4 * ld));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 // bf16 LDS planes: [rows][K] with K+8 elements per row (144-byte rows at K=64: the 16 rows a
 // ds_read_b128 fragment touches start 36 dwords apart, i.e. on distinct 4-bank groups)
 template <int K>

@@ -48,7 +48,7 @@ struct StageX3Args {
 #endif
 
 constexpr int kMaxClsX3 = 8;
-constexpr int LDT = kTileRows + 8;      // transposed planes: [H][64 tile rows (+8 pad)]
+constexpr int XLD = 24;                 // row-major [64][16 (+8 pad)] planes of [deg, onehot(cls) x8, 1, 0..]
 constexpr int kNW = 8;                  // waves per workgroup (two per SIMD)
 constexpr int kThreadsX3 = kNW * 64;
 constexpr int kIdxCap = 1024;           // neighbour entries of one tile kept in LDS; the tail is read from global
@@ -73,7 +73,6 @@ struct X3Smem {
     using S = SplitX3<H>;
     static constexpr int LDP = H + 8;                         // bf16 elements per row-major plane row
     static constexpr int PB = kTileRows * LDP * 2;            // bytes of a row-major plane
-    static constexpr int PT = H * LDT * 2;                    // bytes of a transposed plane
     static constexpr int F32TILE = kTileRows * S::LD * 4;
     static constexpr int SMALL_F = kMaxClsX3 * 3 * H + 3 * H + 3 * H + H + H + kTileRows + kTileRows;   // floats
     // forward
@@ -87,16 +86,15 @@ struct X3Smem {
     static constexpr int fwd_bytes = f_idx + IDX_BYTES;
     // backward
     static constexpr int b_planes = 0;                        // region A: row-major operand planes
-    static constexpr int b_tplanes = b_planes + 4 * PB;       // region B: transposed aggT_hi/lo, hinT_hi/lo
-    static constexpr int b_c = b_tplanes + 4 * PT;            // region C: {pre, dy fp32} then {d_hi, d_lo, dT_hi, dT_lo}
-    static constexpr int C_BYTES = (2 * F32TILE > 2 * PB + 2 * PT) ? 2 * F32TILE : 2 * PB + 2 * PT;
+    static constexpr int b_c = b_planes + 4 * PB;             // region C: {pre, dy fp32} then {d_hi, d_lo}
+    static constexpr int C_BYTES = (2 * F32TILE > 2 * PB) ? 2 * F32TILE : 2 * PB;
     static constexpr int b_small = b_c + C_BYTES;
     static constexpr int b_stat = b_small + SMALL_F * 4;      // 4 floats per row
     static constexpr int b_acc = b_stat + 4 * kTileRows * 4;  // dxt[C*3H], dbc[3H], dbhh[3H], dlnw[H], dlnb[H]
     static constexpr int ACC_F = kMaxClsX3 * 3 * H + 3 * H + 3 * H + H + H;
     static constexpr int b_idx = b_acc + ACC_F * 4;
-    static constexpr int b_xe = b_idx + IDX_BYTES;                 // XeT_hi, XeT_lo: [16][LDT] rows = deg, onehot(cls) x8, 1, 0...
-    static constexpr int bwd_bytes = b_xe + 2 * 16 * LDT * 2;
+    static constexpr int b_xe = b_idx + IDX_BYTES;                 // xe_hi, xe_lo: [64][XLD] columns = deg, onehot(cls) x8, 1, 0...
+    static constexpr int bwd_bytes = b_xe + 2 * kTileRows * XLD * 2;
     static_assert(bwd_bytes <= 160 * 1024, "backward LDS budget");
 };
 
@@ -478,21 +476,23 @@ struct WgradX3 {
     __device__ static int ks0(int w) { return KSPLIT ? (w / T) * KS : 0; }
 };
 
-// acc[t] += D^T[gate cols of tile][64 rows] * X[64 rows][input cols of tile], both from transposed planes
+// acc[t] += D^T[gate cols of tile][64 rows] * X[64 rows][input cols of tile]; both operands are read
+// transposed (ds_read_b64_tr_b16) from the row-major planes the forward-orientation products also use
 template <int H>
-__device__ __forceinline__ void wgrad_x3(f32x4 (&acc)[WgradX3<H>::TPW], const __bf16* dT_hi, const __bf16* dT_lo,
-                                         const __bf16* xT_hi, const __bf16* xT_lo) {
+__device__ __forceinline__ void wgrad_x3(f32x4 (&acc)[WgradX3<H>::TPW], const __bf16* d_hi, const __bf16* d_lo,
+                                         const __bf16* x_hi, const __bf16* x_lo) {
     using W = WgradX3<H>;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    constexpr int LDP = H + 8;
+    const int w = threadIdx.x >> 6;
 #pragma unroll 1
     for (int kk = 0; kk < W::KS; ++kk) {
-        const int ko = 32 * (W::ks0(w) + kk) + 8 * q;
+        const int k0 = 32 * (W::ks0(w) + kk);
 #pragma unroll
         for (int t = 0; t < W::TPW; ++t) {
             const int tl = W::tile_of(w, t);
             const int it = tl / W::HC, jt = tl % W::HC;
-            const bf16x8 ah = ldfrag(dT_hi + (it * 16 + r) * LDT + ko), al = ldfrag(dT_lo + (it * 16 + r) * LDT + ko);
-            const bf16x8 bh = ldfrag(xT_hi + (jt * 16 + r) * LDT + ko), bl = ldfrag(xT_lo + (jt * 16 + r) * LDT + ko);
+            const bf16x8 ah = ldfrag_tr(d_hi, LDP, k0, it * 16), al = ldfrag_tr(d_lo, LDP, k0, it * 16);
+            const bf16x8 bh = ldfrag_tr(x_hi, LDP, k0, jt * 16), bl = ldfrag_tr(x_lo, LDP, k0, jt * 16);
             mma_x3(acc[t], ah, al, bh, bl);
         }
     }
@@ -528,16 +528,10 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
     __bf16* agg_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_planes + M::PB);
     __bf16* hin_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_planes + 2 * M::PB);
     __bf16* hin_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_planes + 3 * M::PB);
-    __bf16* aggT_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_tplanes);
-    __bf16* aggT_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_tplanes + M::PT);
-    __bf16* hinT_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_tplanes + 2 * M::PT);
-    __bf16* hinT_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_tplanes + 3 * M::PT);
     float* s_pre = reinterpret_cast<float*>(smem_raw + M::b_c);
     float* s_dy = reinterpret_cast<float*>(smem_raw + M::b_c + M::F32TILE);
     __bf16* d_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_c);                       // aliases s_pre/s_dy
     __bf16* d_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_c + M::PB);
-    __bf16* dT_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_c + 2 * M::PB);
-    __bf16* dT_lo = reinterpret_cast<__bf16*>(smem_raw + M::b_c + 2 * M::PB + M::PT);
     const SmallVecs sv = stage_small<H>(a, reinterpret_cast<float*>(smem_raw + M::b_small));
     float* s_stat = reinterpret_cast<float*>(smem_raw + M::b_stat);
     float* s_dxt = reinterpret_cast<float*>(smem_raw + M::b_acc);
@@ -545,8 +539,8 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
     float* s_dbhh = s_dbc + 3 * H;
     float* s_dlnw = s_dbhh + 3 * H;
     float* s_dlnb = s_dlnw + H;
-    __bf16* xeT_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_xe);
-    __bf16* xeT_lo = xeT_hi + 16 * LDT;
+    __bf16* xe_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_xe);
+    __bf16* xe_lo = xe_hi + kTileRows * XLD;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
     for (int i = tid; i < M::ACC_F; i += kThreadsX3) s_dxt[i] = 0.f;
     const int wc = w % S::WPC, wr = w / S::WPC;
@@ -584,7 +578,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
         const int64_t base = tile * kTileRows;
         STAMP_BEGIN;
         // ---- A. row phase (independent loads); operand planes row-major (GEMM A operands) and
-        //        transposed (wgrad B operands)
+        //        (they serve the wgrad too, read transposed)
         {
             float4 acc[RPG], own[RPG], dy[RPG];
             float deg[RPG];
@@ -596,19 +590,15 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                 bf16x4 hi, lo;
                 split4(acc[rr], hi, lo);
                 st_bf4(agg_hi + row * LDP + 4 * lr, hi); st_bf4(agg_lo + row * LDP + 4 * lr, lo);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { aggT_hi[(4 * lr + c) * LDT + row] = hi[c]; aggT_lo[(4 * lr + c) * LDT + row] = lo[c]; }
                 split4(own[rr], hi, lo);
                 st_bf4(hin_hi + row * LDP + 4 * lr, hi); st_bf4(hin_lo + row * LDP + 4 * lr, lo);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { hinT_hi[(4 * lr + c) * LDT + row] = hi[c]; hinT_lo[(4 * lr + c) * LDT + row] = lo[c]; }
                 st4(s_dy + row * S::LD + 4 * lr, dy[rr]);
                 if (lr == 0) { sv.deg[row] = deg[rr]; sv.cls[row] = cls[rr]; }
                 if (lr < 16) {
                     const float xe = lr == 0 ? deg[rr] : (lr <= 8 ? (cls[rr] == lr - 1 ? 1.0f : 0.0f) : (lr == 9 ? 1.0f : 0.0f));
                     __bf16 xh, xl;
                     split_bf16(xe, xh, xl);
-                    xeT_hi[lr * LDT + row] = xh; xeT_lo[lr * LDT + row] = xl;
+                    xe_hi[row * XLD + lr] = xh; xe_lo[row * XLD + lr] = xl;
                 }
             }
         }
@@ -724,10 +714,6 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                         d_hi[row * LDP + col] = h[e];
                         d_lo[row * LDP + col] = l[e];
                     }
-                    // transposed copy: this lane's 4 consecutive rows of column `col` are contiguous
-                    const int row0 = (wr * S::RTW + i) * 16 + q * 4;
-                    st_bf4(dT_hi + col * LDT + row0, bf16x4{h[0], h[1], h[2], h[3]});
-                    st_bf4(dT_lo + col * LDT + row0, bf16x4{l[0], l[1], l[2], l[3]});
                 }
             STAMP(10);
             __syncthreads();
@@ -760,15 +746,13 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                 }
             }
             STAMP(12);
-            if (p != 3) wgrad_x3<H>(gWc[g], dT_hi, dT_lo, aggT_hi, aggT_lo);
-            if (p != 2) wgrad_x3<H>(gWhh[g], dT_hi, dT_lo, hinT_hi, hinT_lo);
+            if (p != 3) wgrad_x3<H>(gWc[g], d_hi, d_lo, agg_hi, agg_lo);
+            if (p != 2) wgrad_x3<H>(gWhh[g], d_hi, d_lo, hin_hi, hin_lo);
             if (w < H / 16) {          // wave-uniform: gate-column tile w of the bias-type gradients
 #pragma unroll
-                for (int ks = 0; ks < kTileRows / 32; ++ks) {
-                    const int ko = 32 * ks + 8 * q;
-                    mma_x3(gX[p], ldfrag(dT_hi + (w * 16 + r) * LDT + ko), ldfrag(dT_lo + (w * 16 + r) * LDT + ko),
-                           ldfrag(xeT_hi + r * LDT + ko), ldfrag(xeT_lo + r * LDT + ko));
-                }
+                for (int ks = 0; ks < kTileRows / 32; ++ks)
+                    mma_x3(gX[p], ldfrag_tr(d_hi, LDP, 32 * ks, w * 16), ldfrag_tr(d_lo, LDP, 32 * ks, w * 16),
+                           ldfrag_tr(xe_hi, XLD, 32 * ks, 0), ldfrag_tr(xe_lo, XLD, 32 * ks, 0));
             }
             STAMP(13);
         }

@@ -77,11 +77,12 @@ class Trainer():
         if self.distributed:
             if 'LOCAL_RANK' in os.environ:
                 self.local_rank = int(os.environ['LOCAL_RANK'])
-            self.device = 'cuda:%d' % self.local_rank
-            torch.cuda.set_device(self.local_rank)
+            dev_index = self.local_rank % max(torch.cuda.device_count(), 1)   # one rank per GPU (wraps only in rehearsals)
+            self.device = 'cuda:%d' % dev_index
+            torch.cuda.set_device(dev_index)
             if not torch.distributed.is_initialized():
                 # backend 'nccl' is RCCL on ROCm; rendezvous from the torchrun environment
-                torch.distributed.init_process_group(backend='nccl', init_method='env://')
+                torch.distributed.init_process_group(backend=os.environ.get('MGV_DIST_BACKEND', 'nccl'), init_method='env://')
             self.world_size = torch.distributed.get_world_size()
             self.rank = torch.distributed.get_rank()
             print('Training in distributed mode. Device {}, Process {:}, total {:}.'.format(self.device, self.rank, self.world_size))
