@@ -159,6 +159,13 @@ def main():
               'mgv_struct_stage_bwd_x3': 4.0 * H * (2 * E + 4 * N) + 8.0 * (N + E),
               'mgv_struct_stage_fwd_x3': 4.0 * H * (E + 2 * N) + 4.0 * (2 * N + E)}.get(dom)
         roof = {'kernel': dom, 'launch_ms': per_launch_s * 1e3, 'traffic': None}
+        try:        # HBM bytes per launch from the committed PMC passes (same workload only)
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_x3_pmc_traffic.json')))
+            if pmc.get('N') == N and dom in pmc['kernels']:
+                roof['traffic'] = pmc['kernels'][dom]['hbm_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/r01_x3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)'
+        except (OSError, ValueError, KeyError):
+            pass
         if dom.endswith('_x3') and by is not None:
             ach = by / per_launch_s / 1e9          # split-precision MFMA makes the half round HBM-bound
             roof.update(bound='hbm', achieved=ach, peak=PEAK_HBM_GBPS, unit='GB/s', frac=ach / PEAK_HBM_GBPS,

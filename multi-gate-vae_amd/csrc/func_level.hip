@@ -39,13 +39,15 @@ struct LevelArgs {
     float* d_attn_u; float* dWvc; float* dbvc; float* dbih; float* dbhh;
 };
 
-template <int H>
+template <int H, bool BWD = true>
 struct LevelSmem {
     using S = WaveSplit<H>;
     static constexpr int LDZ = 2 * H + 4;
     static constexpr int off_z = 0;                                  // zbar tile [64][2H+4]
-    static constexpr int off_o = off_z + kTileRows * LDZ;            // fwd: output tile / bwd: dh then dG tiles [64][H+4]
-    static constexpr int off_u = off_o + kTileRows * S::LD;
+    // second tile region [64][2H+4]: backward keeps dh, then the dG tiles ([64][H+4]) in it and finally
+    // overlays d(zbar) ([64][2H+4]) on it; forward needs no second region (its output tile reuses off_z)
+    static constexpr int off_o = off_z + kTileRows * LDZ;
+    static constexpr int off_u = BWD ? off_o + kTileRows * LDZ : off_o;    // forward: no second region
     static constexpr int off_bvc = off_u + 2 * H;
     static constexpr int off_bih = off_bvc + 3 * H;
     static constexpr int off_bhh = off_bih + 3 * H;
@@ -54,8 +56,8 @@ struct LevelSmem {
     static constexpr int off_inv = off_m + kTileRows;                // 1/(S+1e-16) per row
     static constexpr int off_node = off_inv + kTileRows;             // node id per row (int)
     static constexpr int fwd_floats = off_node + kTileRows;
-    static constexpr int off_dz = fwd_floats;                        // d(zbar) tile [64][2H+4]
-    static constexpr int off_gu = off_dz + kTileRows * LDZ;          // [2H]
+    static constexpr int off_dz = off_o;                             // d(zbar) tile [64][2H+4] over the dG region
+    static constexpr int off_gu = fwd_floats;                        // [2H]
     static constexpr int off_dbvc = off_gu + 2 * H;
     static constexpr int off_dbih = off_dbvc + 3 * H;
     static constexpr int off_dbhh = off_dbih + 3 * H;
@@ -89,9 +91,9 @@ __device__ __forceinline__ void attn_row(const LevelArgs& a, int64_t node, const
     if (e1 == e0) { m = 0.f; }
 }
 
-template <int H>
+template <int H, bool BWD>
 __device__ __forceinline__ void level_stage_vectors(const LevelArgs& a, int g, float* smem) {
-    using M = LevelSmem<H>;
+    using M = LevelSmem<H, BWD>;
     for (int i = threadIdx.x; i < 2 * H; i += kThreads) smem[M::off_u + i] = a.attn_u[(int64_t)g * 2 * H + i];
     for (int i = threadIdx.x; i < 3 * H; i += kThreads) {
         smem[M::off_bvc + i] = a.bvc[(int64_t)g * 3 * H + i];
@@ -137,16 +139,16 @@ __device__ __forceinline__ void level_gemm(const float* Wvc_g, const float* s_z,
 template <int H>
 __global__ __launch_bounds__(kThreads) void k_level_fwd(LevelArgs a) {
     using S = WaveSplit<H>;
-    using M = LevelSmem<H>;
+    using M = LevelSmem<H, false>;
     constexpr int LDZ = M::LDZ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_z = smem + M::off_z;
-    float* s_o = smem + M::off_o;
+    float* s_o = smem + M::off_z;      // reused once the MFMAs have consumed zbar
     float* s_sa = smem + M::off_sa;
     int* s_node = reinterpret_cast<int*>(smem + M::off_node);
     const int tile = a.tile_begin + blockIdx.x;
     const int start = a.tile_start[tile], count = a.tile_count[tile], g = a.tile_slot[tile];
-    level_stage_vectors<H>(a, g, smem);
+    level_stage_vectors<H, false>(a, g, smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wc = w % S::WPC, wr = w / S::WPC;
     const int grp = tid / S::LPR, lr = tid % S::LPR;
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(kThreads) void k_level_fwd(LevelArgs a) {
     __syncthreads();
     f32x4 ar[S::RTW][S::HCW], az[S::RTW][S::HCW], an[S::RTW][S::HCW];
     level_gemm<H>(a.Wvc + (int64_t)g * 3 * H * 2 * H, s_z, ar, az, an);
+    __syncthreads();                   // s_o overlays s_z
     const float* s_bvc = smem + M::off_bvc; const float* s_bih = smem + M::off_bih; const float* s_bhh = smem + M::off_bhh;
 #pragma unroll
     for (int i = 0; i < S::RTW; ++i)
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void k_level_bwd(LevelArgs a) {
     float* s_dbvc = smem + M::off_dbvc; float* s_dbih = smem + M::off_dbih; float* s_dbhh = smem + M::off_dbhh;
     const int tile = a.tile_begin + blockIdx.x;
     const int start = a.tile_start[tile], count = a.tile_count[tile], g = a.tile_slot[tile];
-    level_stage_vectors<H>(a, g, smem);
+    level_stage_vectors<H, true>(a, g, smem);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wc = w % S::WPC, wr = w / S::WPC;
     const int grp = tid / S::LPR, lr = tid % S::LPR;
@@ -356,7 +359,8 @@ __global__ __launch_bounds__(kThreads) void k_level_bwd(LevelArgs a) {
                 atomicAdd(dWvc_g + (int64_t)(p * H + it * 16 + q * 4 + e) * 2 * H + jt * 16 + r, gw[t][e]);
         }
     }
-    // ---- 5. d(zbar) tile to LDS (row layout needed for the attention backward)
+    // ---- 5. d(zbar) tile to LDS (row layout needed for the attention backward); it overlays the dG tile
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < S2::RTW; ++i)
 #pragma unroll
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(kThreads) void k_level_pull_inactive(LevelArgs a) {
 template <int H>
 int launch_level(bool bwd, const LevelArgs& a, int ntiles, hipStream_t st) {
     using M = LevelSmem<H>;
-    const size_t shm = (bwd ? M::bwd_floats : M::fwd_floats) * sizeof(float);
+    const size_t shm = (bwd ? (size_t)M::bwd_floats : (size_t)LevelSmem<H, false>::fwd_floats) * sizeof(float);
     if (bwd) {
         static bool set_b = false;
         if (!set_b) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_bwd<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_b = true; }
