@@ -594,11 +594,11 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                 st_bf4(hin_hi + row * LDP + 4 * lr, hi); st_bf4(hin_lo + row * LDP + 4 * lr, lo);
                 st4(s_dy + row * S::LD + 4 * lr, dy[rr]);
                 if (lr == 0) { sv.deg[row] = deg[rr]; sv.cls[row] = cls[rr]; }
-                if (lr < 16) {
-                    const float xe = lr == 0 ? deg[rr] : (lr <= 8 ? (cls[rr] == lr - 1 ? 1.0f : 0.0f) : (lr == 9 ? 1.0f : 0.0f));
+                for (int jx = lr; jx < 16; jx += S::LPR) {       // the row group's lanes share the 16 extra columns
+                    const float xe = jx == 0 ? deg[rr] : (jx <= 8 ? (cls[rr] == jx - 1 ? 1.0f : 0.0f) : (jx == 9 ? 1.0f : 0.0f));
                     __bf16 xh, xl;
                     split_bf16(xe, xh, xl);
-                    xe_hi[row * XLD + lr] = xh; xe_lo[row * XLD + lr] = xl;
+                    xe_hi[row * XLD + jx] = xh; xe_lo[row * XLD + jx] = xl;
                 }
             }
         }

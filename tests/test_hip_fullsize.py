@@ -1,0 +1,116 @@
+"""GPU checks at BASELINE.json's full sizes, where the oracle cannot run in seconds: size-independent
+properties of the path.
+
+  * exact-fp32 vs bf16x3 kernels agree on embeddings and losses (1e-4 on losses, the north_star bar);
+  * relabelling the nodes (a random permutation of ids, edges/levels/labels carried along) leaves the
+    three losses unchanged and permutes the embeddings;
+  * a batch is the disjoint union of its graphs: per-graph embeddings do not depend on batch mates;
+  * a train step on config 3 (MIG, 3-input MAJ gates) and config 5 (XMG, 256k-node graphs, 5 aggregators)
+    shapes runs and produces finite losses and gradients.
+"""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _model(ctype, dev, seed=0):
+    import deepgate
+    torch.manual_seed(seed)
+    enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=64, s_rounds=4, t_rounds=4, layernorm=True)
+    mod = {'aig': deepgate.dg_ae_model_aig, 'mig': deepgate.dg_ae_model_mig, 'xmg': deepgate.dg_ae_model_xmg}[ctype]
+    return mod.Model(struct_encoder=enc, dim_hidden=64).to(dev)
+
+
+def _losses(model, batch):
+    import deepgate
+    from deepgate import ops
+    with torch.no_grad():
+        hs, hf = model(batch)
+        rl, _, _ = model.recon_loss(hs, batch.edge_index, batch.neg_edge_index, want_pred=False)
+        prob = model.pred_prob(hf)
+        pl = ops.l1_loss(prob, batch.prob)
+        fl = ops.func_loss(hf, batch.tt_pair_index, batch.tt_sim)
+    return hs, hf, torch.stack([rl, pl, fl]).double().cpu().numpy()
+
+
+def test_cfg2_full_size_precision_modes_and_relabelling():
+    dev = _dev()
+    import deepgate
+    from deepgate import ops, synthetic as syn
+    arrays = syn.make_batch(2)                       # 64 x 65,536-node AIGs: N = 4,194,304
+    N = arrays['num_nodes']
+    model = _model('aig', dev).eval()
+    batch = deepgate.CircuitBatch.from_arrays(arrays, device=dev)
+    old = ops.PRECISION
+    try:
+        ops.PRECISION = 'f32'
+        hs32, hf32, l32 = _losses(model, batch)
+        ops.PRECISION = 'x3'
+        hs3, hf3, l3 = _losses(model, batch)
+    finally:
+        ops.PRECISION = old
+    assert np.all(np.isfinite(l32)) and np.all(np.isfinite(l3))
+    np.testing.assert_allclose(l3, l32, rtol=1e-4, atol=1e-5)                     # loss match 1e-4
+    assert float((hs3 - hs32).abs().max()) <= 2e-4 * max(1.0, float(hs32.abs().max()))
+    assert float((hf3 - hf32).abs().max()) <= 2e-4 * max(1.0, float(hf32.abs().max()))
+    del hs32, hf32
+
+    # relabel: new id = perm[old id]
+    rng = np.random.Generator(np.random.PCG64(7))
+    perm = rng.permutation(N)
+    inv = np.empty_like(perm); inv[perm] = np.arange(N)
+    rel = {'x': arrays['x'][inv], 'gate': arrays['gate'][inv], 'forward_level': arrays['forward_level'][inv],
+           'forward_index': np.arange(N, dtype=np.int64), 'prob': arrays['prob'][inv],
+           'edge_index': perm[arrays['edge_index']], 'tt_pair_index': perm[arrays['tt_pair_index']],
+           'tt_sim': arrays['tt_sim'], 'neg_edge_index': perm[arrays['neg_edge_index']], 'num_nodes': N}
+    batch_r = deepgate.CircuitBatch.from_arrays(rel, device=dev)
+    hs_r, hf_r, l_r = _losses(model, batch_r)
+    np.testing.assert_allclose(l_r, l3, rtol=2e-5, atol=1e-6)
+    p = torch.from_numpy(perm).to(dev)
+    assert float((hs_r[p] - hs3).abs().max()) <= 1e-4 * max(1.0, float(hs3.abs().max()))
+    assert float((hf_r[p] - hf3).abs().max()) <= 1e-4 * max(1.0, float(hf3.abs().max()))
+
+
+def test_graphs_of_a_batch_do_not_interact():
+    dev = _dev()
+    import deepgate
+    from deepgate import synthetic as syn
+    model = _model('aig', dev).eval()
+    graphs = [syn.make_graph('aig', 65536, 120, 2000 + i, n_inputs=4096) for i in range(3)]
+    b3 = deepgate.CircuitBatch.from_arrays(syn.collate(graphs), device=dev)
+    b1 = deepgate.CircuitBatch.from_arrays(syn.collate(graphs[1:2]), device=dev)
+    with torch.no_grad():
+        hs3, hf3 = model(b3)
+        hs1, hf1 = model(b1)
+    sl = slice(65536, 2 * 65536)
+    assert float((hs3[sl] - hs1).abs().max()) <= 1e-5 * max(1.0, float(hs1.abs().max()))
+    assert float((hf3[sl] - hf1).abs().max()) <= 1e-5 * max(1.0, float(hf1.abs().max()))
+
+
+@pytest.mark.parametrize('cfg,ctype,batch', [(3, 'mig', 8), (5, 'xmg', 2)])
+def test_train_step_on_other_baseline_shapes(cfg, ctype, batch):
+    dev = _dev()
+    import deepgate
+    from deepgate import synthetic as syn
+    model = _model(ctype, dev).train()
+    tr = deepgate.Trainer(types.SimpleNamespace(model='DG_AE'), model, training_id='fs', save_dir='/tmp/mgv_fullsize', lr=1e-4,
+                          rc_prob_func_weight=[1.0, 4.0, 4.0], device='cuda:0', batch_size=batch, distributed=False)
+    b = deepgate.CircuitBatch.from_arrays(syn.make_batch(cfg, batch=batch), device=dev)
+    ls = tr.train_step(b)
+    vals = [float(ls[k]) for k in ('recon_loss', 'prob_loss', 'func_loss')]
+    assert all(np.isfinite(v) for v in vals), vals
+    f = tr.optimizer.flat_buffers()
+    assert bool(torch.isfinite(f['grad']).all()) and float(f['grad'].abs().sum()) > 0
+    assert bool(torch.isfinite(f['param']).all())
+    cnt = ls['confusion'].cpu().numpy()
+    assert int(cnt.sum()) == b.edge_index.shape[1] + b.neg_edge_index.shape[1]
