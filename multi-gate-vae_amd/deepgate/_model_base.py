@@ -56,6 +56,10 @@ class FunctionalModel(nn.Module):
         enc = getattr(self, self.ENCODER_ATTR)
         s, t = enc(None, None, G.edge_index, plan=plan, classes=(rows, plan.xcls))
         hs = ops.linear(s, self.hs_linear.weight, self.hs_linear.bias, x2=t)
+        # the reconstruction branch only needs hs: Trainer.run_batch may start it on a second stream as soon
+        # as this event has fired, next to the (latency-bound, GPU-underfilling) level sweep
+        self._hs_ready = torch.cuda.Event()
+        self._hs_ready.record()
         hf = ops.FuncSweepFn.apply(plan, hs, *self._sweep_params())
         return hs, hf
 

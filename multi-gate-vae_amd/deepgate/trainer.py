@@ -97,6 +97,8 @@ class Trainer():
             for b in self.model.buffers():
                 torch.distributed.broadcast(b.data, 0)
         self.model_epoch = 0
+        self.overlap = os.environ.get('MGV_OVERLAP', '1') != '0'     # second stream for the reconstruction branch
+        self._side = None
         if self.local_rank == 0:
             self.logger = Logger(self.log_path)
 
@@ -151,8 +153,23 @@ class Trainer():
             keys = getattr(batch, '_mgv_edge_keys', None)
             if keys is None:
                 keys = batch._mgv_edge_keys = sorted_edge_keys(batch.edge_index, batch.num_nodes)
-        loss, pred_bin, gt_bin = self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred, edge_keys=keys,
-                                                       plan=getattr(batch, '_mgv_plan', None))
+        side = self._side_stream() if (self.overlap and hs.is_cuda and hasattr(self.model, '_hs_ready')) else None
+        if side is not None:
+            # reconstruction branch (hs_decompose -> decoder loss) on a second HIP stream: it runs beside the level
+            # sweep forward and, because autograd replays a node on its forward stream, beside the sweep backward
+            main = torch.cuda.current_stream()
+            side.wait_event(self.model._hs_ready)
+            hs.record_stream(side)
+            with torch.cuda.stream(side):
+                loss, pred_bin, gt_bin = self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred,
+                                                               edge_keys=keys, plan=getattr(batch, '_mgv_plan', None))
+            main.wait_stream(side)
+            for t in (loss, pred_bin, gt_bin, self.model.last_confusion):
+                if t is not None:
+                    t.record_stream(main)
+        else:
+            loss, pred_bin, gt_bin = self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred, edge_keys=keys,
+                                                           plan=getattr(batch, '_mgv_plan', None))
         loss_status = {'recon_loss': loss, 'pred_bin': pred_bin, 'gt_bin': gt_bin}
         if 'VAE' in getattr(self.args, 'model', '') and hasattr(self.model, 'kl_loss'):
             s_kl, t_kl = self.model.kl_loss()
@@ -162,6 +179,11 @@ class Trainer():
         loss_status['func_loss'] = ops.func_loss(hf, batch['tt_pair_index'], batch['tt_sim'])
         loss_status['confusion'] = self.model.last_confusion
         return loss_status
+
+    def _side_stream(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     def weighted_loss(self, loss_status):
         w = self.rc_prob_func_weight
@@ -173,6 +195,8 @@ class Trainer():
         loss_status = self.run_batch(batch, want_pred=want_pred)
         loss = self.weighted_loss(loss_status)
         loss.backward()
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)      # backward work queued on the second stream
         self.optimizer.step()
         return loss_status
 
