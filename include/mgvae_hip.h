@@ -105,6 +105,24 @@ int mgv_func_sweep_bwd(int H, int64_t N, int T, int num_levels, const int32_t* l
                        const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc, float* d_attn_u,
                        float* dWvc, float* dbvc, float* dbih, float* dbhh, void* stream);
 
+/* the sweep on bf16x3 split-precision MFMA (H in {32, 64}); same arguments except the weights:
+ * wpack_bf16[T][4][6H^2] = per slot {Wvc_hi, Wvc_lo, WvcT_hi, WvcT_lo} as bf16 in MFMA fragment order
+ * (blocks (row tile, k-step) of 512 elements, lane 16q+r holds W[16 rt + r][32 ks + 8q .. +7]);
+ * dWvc stays fp32 [T][3H][2H] */
+int mgv_func_sweep_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                          const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
+                          const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src, const float* hs,
+                          float* hf, const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
+                          const float* bhh, void* stream);
+int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                          const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
+                          const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src,
+                          const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_slot,
+                          const uint8_t* gslot, const float* hs, const float* hf, const float* attn_u,
+                          const void* wpack_bf16, const float* bvc, const float* bih, const float* bhh,
+                          const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc, float* d_attn_u,
+                          float* dWvc, float* dbvc, float* dbih, float* dbhh, void* stream);
+
 /* ---- inner-product decoder and reconstruction loss (digae_layer.py:26-29, dg_ae_model_aig.py:108-130).
  * s, t: row pointers with common row stride ld (the two halves of hs_decompose's output);
  * edge lists are int64 like the reference's edge_index rows. */

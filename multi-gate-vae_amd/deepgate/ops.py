@@ -48,6 +48,17 @@ def stage_wpack(Wc, Whh):
     return torch.cat(parts).contiguous()
 
 
+def sweep_wpack(Wvc):
+    """bf16 weight pack of mgv_func_sweep_*_x3 from Wvc [T, 3H, 2H]: per slot [Wvc_hi, Wvc_lo, WvcT_hi, WvcT_lo],
+    each block in fragment order."""
+    slots = []
+    for g in range(Wvc.shape[0]):
+        for w in (Wvc[g], Wvc[g].t().contiguous()):
+            hi, lo = split_bf16(w)
+            slots += [frag_order(hi), frag_order(lo)]
+    return torch.cat(slots).contiguous()
+
+
 def _zeros_like_params(*ts):
     return [torch.zeros_like(t) for t in ts]
 
@@ -266,10 +277,16 @@ class FuncSweepFn(torch.autograd.Function):
         assert plan.has_levels and plan.num_slots == T and plan.N == N
         hf = torch.zeros(N, H, dtype=F32, device=hsd.device)
         ltp = (_hip.ctypes.c_int32 * len(plan.level_tile_ptr))(*plan.level_tile_ptr)
-        _hip.call('mgv_func_sweep_fwd', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.tile_start),
-                  ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
-                  *[ptr(t) for t in par])
-        ctx.plan, ctx.par, ctx.ltp = plan, par, ltp
+        wpack = sweep_wpack(par[1]) if use_x3(H) else None
+        if wpack is not None:
+            _hip.call('mgv_func_sweep_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.tile_start),
+                      ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
+                      ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]))
+        else:
+            _hip.call('mgv_func_sweep_fwd', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.tile_start),
+                      ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
+                      *[ptr(t) for t in par])
+        ctx.plan, ctx.par, ctx.ltp, ctx.wpack = plan, par, ltp, wpack
         ctx.save_for_backward(hsd, hf)
         return hf
 
@@ -286,6 +303,13 @@ class FuncSweepFn(torch.autograd.Function):
         alpha = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
         dsc = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
         grads = [torch.zeros_like(t) for t in par]
+        if ctx.wpack is not None:
+            _hip.call('mgv_func_sweep_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.tile_start),
+                      ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr),
+                      ptr(plan.out_dst), ptr(plan.out_slot), ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]),
+                      ptr(ctx.wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]), ptr(ghf), ptr(ghs), ptr(dzb), ptr(alpha),
+                      ptr(dsc), *[ptr(g) for g in grads])
+            return (None, ghs, *grads)
         WvcT = par[1].transpose(1, 2).contiguous()
         _hip.call('mgv_func_sweep_bwd', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.tile_start),
                   ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr),
