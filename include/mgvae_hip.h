@@ -105,23 +105,32 @@ int mgv_func_sweep_bwd(int H, int64_t N, int T, int num_levels, const int32_t* l
                        const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc, float* d_attn_u,
                        float* dWvc, float* dbvc, float* dbih, float* dbhh, void* stream);
 
-/* the sweep on bf16x3 split-precision MFMA (H in {32, 64}); same arguments except the weights:
+/* the sweep on bf16x3 split-precision MFMA (H in {32, 64}, T <= 6).  Differences from the fp32 entry points:
  * wpack_bf16[T][4][6H^2] = per slot {Wvc_hi, Wvc_lo, WvcT_hi, WvcT_lo} as bf16 in MFMA fragment order
  * (blocks (row tile, k-step) of 512 elements, lane 16q+r holds W[16 rt + r][32 ks + 8q .. +7]);
- * dWvc stays fp32 [T][3H][2H] */
+ * order_span[n_active][4] = {in_ptr[v], in_ptr[v+1], out_ptr[v], out_ptr[v+1]} of v = order[i] (the CSR
+ * spans in sweep order, so a tile reaches its edge lists with one load per row).
+ * Backward: no float atomics per tile.  The level kernels leave their rows' gate gradients and zbar rows in
+ * `scratch` (sweep order) and one weight-gradient kernel per slot forms dWvc afterwards from the slot's tile
+ * list: slot_tiles[num_tiles] = tile ids grouped by slot, slot_tile_ptr_host = HOST array [T+1] of offsets into
+ * it; the small gradients (d_attn_u, dbvc, dbih, dbhh) are summed per workgroup in `scratch` too.
+ * scratch_elems >= n_active * 5H + (tiles of the widest level) * T * 11H floats, n_active = length of `order`.
+ * dWvc stays fp32 [T][3H][2H] and is ADDED to; ghs[N][H] is WRITTEN for every node (no zero fill needed). */
 int mgv_func_sweep_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                          const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
-                          const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src, const float* hs,
-                          float* hf, const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
-                          const float* bhh, void* stream);
+                          const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
+                          const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
+                          const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
+                          const void* wpack_bf16, const float* bvc, const float* bih, const float* bhh, void* stream);
 int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                          const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
-                          const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src,
-                          const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_slot,
-                          const uint8_t* gslot, const float* hs, const float* hf, const float* attn_u,
-                          const void* wpack_bf16, const float* bvc, const float* bih, const float* bhh,
-                          const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc, float* d_attn_u,
-                          float* dWvc, float* dbvc, float* dbih, float* dbhh, void* stream);
+                          const int32_t* order, const int32_t* order_span, int64_t n_active,
+                          const int32_t* tile_start, const int32_t* tile_count, const int32_t* tile_slot,
+                          const int32_t* slot_tiles, const int32_t* slot_tile_ptr_host, const int32_t* in_ptr,
+                          const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                          const int32_t* out_slot, const uint8_t* gslot, const float* hs, const float* hf,
+                          const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
+                          const float* bhh, const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc,
+                          float* d_attn_u, float* dWvc, float* dbvc, float* dbih, float* dbhh, float* scratch,
+                          int64_t scratch_elems, void* stream);
 
 /* ---- inner-product decoder and reconstruction loss (digae_layer.py:26-29, dg_ae_model_aig.py:108-130).
  * s, t: row pointers with common row stride ld (the two halves of hs_decompose's output);

@@ -1,21 +1,36 @@
-// Levelised functional sweep on bf16x3 split-precision MFMA (mgv_x3.h): same operator, arguments and
-// phases as func_level.hip, whose header describes the math.  Differences: the zbar tile and the gate
-// gradients live in LDS as bf16 hi/lo planes, the three dense products (recompute, dgrad, wgrad) run on
-// v_mfma_f32_16x16x32_bf16, the wgrad reads its operands transposed (ds_read_b64_tr_b16) from the same
-// row-major planes, and the weights arrive pre-split in MFMA fragment order:
-//   per slot:  Wvc_hi | Wvc_lo   ([3H][2H], blocks (row tile, k-step))   forward / recompute B operands
-//              WvcT_hi | WvcT_lo ([2H][3H])                               dgrad B operands
+// Levelised functional sweep on bf16x3 split-precision MFMA (mgv_x3.h): same operator and phases as
+// func_level.hip, whose header describes the math.  Differences:
+//   * the zbar tile and the gate gradients live in LDS as bf16 hi/lo planes; recompute, dgrad and wgrad run on
+//     v_mfma_f32_16x16x32_bf16; the wgrad reads both operands transposed (ds_read_b64_tr_b16) from the same
+//     row-major planes; weights arrive pre-split in MFMA fragment order, per slot
+//         Wvc_hi | Wvc_lo   ([3H][2H], blocks (row tile, k-step))   forward / recompute B operands
+//         WvcT_hi | WvcT_lo ([2H][3H])                               dgrad B operands
+//   * a level is ONE round of tiles on the chip (<= 2 per CU at the baseline shapes), so a level costs one
+//     tile's dependent-load chain.  The chain is cut to  span -> edge lists -> rows : a tile first stages its
+//     rows' CSR spans (order_span, one 16-byte load per row), then its in-/out-edge lists and the per-edge
+//     scalars (alpha, d score, consumer gate slot) in LDS with one thread per edge, and only then gathers
+//     rows, all of a row's loads in flight together.  8 waves per workgroup, two rows per 16-lane group.
 #include "mgv_x3.h"
+#include "mgv_stamps.h"
+#include <algorithm>
 #include "../../include/mgvae_hip.h"
 
 namespace mgv {
 
 constexpr uint8_t kNoGateX = 255;
+constexpr int kLW = 8;                 // waves per workgroup
+constexpr int kLT = 64 * kLW;          // threads per workgroup
+constexpr int kInCap = 4;              // in-edges per row staged in LDS
+constexpr int kInRegs = 3;             // ... of which this many source rows are gathered together (longer lists continue one by one)
+constexpr int kOutCap = 16;            // out-edges per row staged in LDS
+constexpr int kOutChunk = 2;           // consumer rows in flight per lane while pulling
+constexpr int kMaxSlots = 6;           // gate types whose attention vectors are kept in LDS
 
 struct LevelX3Args {
+    unsigned long long* stamps;   // diagnostic build only (MGV_STAMPS)
     int64_t N;
     int T;
-    const int32_t* order; const int32_t* tile_start; const int32_t* tile_count; const int32_t* tile_slot;
+    const int32_t* order; const int32_t* order_span; const int32_t* tile_start; const int32_t* tile_count; const int32_t* tile_slot;
     int tile_begin;
     const int32_t* in_ptr; const int32_t* in_src;
     const float* hs; float* hf;
@@ -25,56 +40,173 @@ struct LevelX3Args {
     const int32_t* out_ptr; const int32_t* out_dst; const int32_t* out_slot; const uint8_t* gslot;
     const float* ghf; float* ghs; float* dzb; float* alpha; float* dsc;
     float* d_attn_u; float* dWvc; float* dbvc; float* dbih; float* dbhh;
+    float* wslab;          // [tiles of the widest level][T][11H]: per-workgroup sums of gu, dbvc, dbih, dbhh
+    float* dgrows;         // [n_active][3H] gate gradients and
+    float* zrows;          // [n_active][2H] zbar rows in sweep order, for the weight-gradient kernel
+    const int32_t* slot_tiles;   // tiles grouped by slot
+};
+
+// kLW waves over a (64 rows) x COLS output: across column tiles first, then row tiles
+template <int COLS>
+struct SplitL {
+    static constexpr int CT = COLS / 16;
+    static constexpr int WPC = CT < kLW ? CT : kLW;
+    static constexpr int WPR = kLW / WPC;
+    static_assert(WPR <= 4, "more waves than 16-row tiles");
+    static constexpr int RTW = 4 / WPR;
+    static constexpr int HCW = CT / WPC;
+    static_assert(HCW == 1, "one column tile per wave");
 };
 
 template <int H>
 struct LvlSmem {
-    using S = WaveSplit<H>;
+    static constexpr int LPR = H / 4;                         // lanes per row
+    static constexpr int GROUPS = kLT / LPR;                  // rows in flight
+    static constexpr int RPG = kTileRows / GROUPS;            // rows per lane group
+    static_assert(RPG >= 1 && RPG * GROUPS == kTileRows, "row groups must tile the 64 rows");
+    static constexpr int LDO = H + 4;                         // fp32 output / dh tile row
     static constexpr int LDZP = 2 * H + 8;                    // bf16 elements per zbar plane row
     static constexpr int LDGP = H + 8;                        // bf16 elements per gate-gradient plane row
     static constexpr int LDZF = 2 * H + 4;                    // fp32 d(zbar) tile row
     static constexpr int ZPB = kTileRows * LDZP * 2;          // bytes of one zbar plane
     static constexpr int GPB = kTileRows * LDGP * 2;
+    static constexpr int DHB = kTileRows * LDO * 4;
     static constexpr int o_zhi = 0;
     static constexpr int o_zlo = o_zhi + ZPB;
-    // forward: output tile fp32 [64][H+4] reuses the zbar planes
+    static_assert(DHB <= 2 * ZPB, "forward output tile reuses the zbar planes");
+    static constexpr int SMALL_F = kMaxSlots * 2 * H + 9 * H + 3 * kTileRows;   // u of every slot, bvc/bih/bhh, sa/m/inv
+    static constexpr int IDX_B = kTileRows * 4 + kTileRows * 16 + kTileRows * kInCap * 4;   // node, span, in-edge sources
+    // forward
     static constexpr int o_small_f = o_zlo + ZPB;
-    static constexpr int SMALL_F = 2 * H + 9 * H + 3 * kTileRows + kTileRows;     // u, bvc/bih/bhh, sa/m/inv, node
-    static constexpr int fwd_bytes = o_small_f + SMALL_F * 4;
-    // backward: region R after the planes: dh fp32, then gate-gradient planes, then d(zbar) fp32
+    static constexpr int o_idx_f = o_small_f + SMALL_F * 4;
+    static constexpr int fwd_bytes = o_idx_f + IDX_B;
+    // backward: region R after the planes = dh fp32 | staged out-edges, then the gate-gradient planes, then d(zbar) fp32
+    static constexpr int OUT_B = kTileRows * kOutCap * (4 + 4 + 4 + 1);   // consumer, alpha, d score, consumer slot
     static constexpr int o_r = o_zlo + ZPB;
-    static constexpr int R_BYTES = kTileRows * LDZF * 4;
-    static_assert(2 * GPB <= R_BYTES && kTileRows * (H + 4) * 4 <= R_BYTES, "region R");
+    static constexpr int o_out = o_r + DHB;
+    static constexpr int R_BYTES = (kTileRows * LDZF * 4 > DHB + OUT_B) ? kTileRows * LDZF * 4 : DHB + OUT_B;
+    static_assert(2 * GPB <= R_BYTES, "region R");
     static constexpr int o_small_b = o_r + R_BYTES;
     static constexpr int o_acc = o_small_b + SMALL_F * 4;     // gu[2H], dbvc, dbih, dbhh [3H each]
-    static constexpr int bwd_bytes = o_acc + (2 * H + 9 * H) * 4;
+    static constexpr int o_idx_b = o_acc + (2 * H + 9 * H) * 4;
+    static constexpr int bwd_bytes = o_idx_b + IDX_B;
+    static_assert(bwd_bytes <= 80 * 1024, "two backward workgroups per CU");
 };
 
-struct LvlSmall { float* u; float* bvc; float* bih; float* bhh; float* sa; float* m; float* inv; int* node; };
+struct LvlSmall { float* uall; float* u; float* bvc; float* bih; float* bhh; float* sa; float* m; float* inv; };
+struct LvlIdx { int* node; int4* span; int* insrc; };
 
 template <int H>
 __device__ __forceinline__ LvlSmall lvl_small(const LevelX3Args& a, int g, float* base) {
     LvlSmall v;
-    v.u = base; v.bvc = v.u + 2 * H; v.bih = v.bvc + 3 * H; v.bhh = v.bih + 3 * H;
+    v.uall = base; v.u = base + g * 2 * H; v.bvc = base + kMaxSlots * 2 * H; v.bih = v.bvc + 3 * H; v.bhh = v.bih + 3 * H;
     v.sa = v.bhh + 3 * H; v.m = v.sa + kTileRows; v.inv = v.m + kTileRows;
-    v.node = reinterpret_cast<int*>(v.inv + kTileRows);
-    for (int i = threadIdx.x; i < 2 * H; i += kThreads) v.u[i] = a.attn_u[(int64_t)g * 2 * H + i];
-    for (int i = threadIdx.x; i < 3 * H; i += kThreads) {
+    for (int i = threadIdx.x; i < a.T * 2 * H; i += kLT) v.uall[i] = a.attn_u[i];
+    for (int i = threadIdx.x; i < 3 * H; i += kLT) {
         v.bvc[i] = a.bvc[(int64_t)g * 3 * H + i]; v.bih[i] = a.bih[(int64_t)g * 3 * H + i]; v.bhh[i] = a.bhh[(int64_t)g * 3 * H + i];
     }
     return v;
 }
 
-// attention over the in-edges of `node` (online softmax), as in func_level.hip
+__device__ __forceinline__ LvlIdx lvl_idx(unsigned char* base) {
+    LvlIdx x;
+    x.span = reinterpret_cast<int4*>(base);
+    x.node = reinterpret_cast<int*>(base + kTileRows * 16);
+    x.insrc = x.node + kTileRows;
+    return x;
+}
+
+// rows' node ids and CSR spans {in0, in1, out0, out1}; padding rows get node -1 and empty spans
+__device__ __forceinline__ void stage_spans(const LevelX3Args& a, int start, int count, const LvlIdx& x) {
+    if (threadIdx.x < kTileRows) {
+        const int row = threadIdx.x;
+        int node = -1;
+        int4 sp = make_int4(0, 0, 0, 0);
+        if (row < count) {
+            node = a.order[start + row];
+            sp = *reinterpret_cast<const int4*>(a.order_span + 4 * (int64_t)(start + row));
+        }
+        x.node[row] = node;
+        x.span[row] = sp;
+    }
+}
+
+__device__ __forceinline__ void stage_in_edges(const LevelX3Args& a, const LvlIdx& x) {
+    if (threadIdx.x < kTileRows * kInCap) {
+        const int row = threadIdx.x / kInCap, k = threadIdx.x % kInCap;
+        const int4 sp = x.span[row];
+        if (sp.x + k < sp.y) x.insrc[threadIdx.x] = a.in_src[sp.x + k];
+    }
+}
+
+struct OutStage { int* c; float* al; float* ds; uint8_t* gc; };
+
+__device__ __forceinline__ OutStage out_stage(unsigned char* base) {
+    OutStage o;
+    o.c = reinterpret_cast<int*>(base);
+    o.al = reinterpret_cast<float*>(base + kTileRows * kOutCap * 4);
+    o.ds = reinterpret_cast<float*>(base + kTileRows * kOutCap * 8);
+    o.gc = reinterpret_cast<uint8_t*>(base + kTileRows * kOutCap * 12);
+    return o;
+}
+
+__device__ __forceinline__ void stage_out_edges(const LevelX3Args& a, const LvlIdx& x, const OutStage& o) {
+    for (int i = threadIdx.x; i < kTileRows * kOutCap; i += kLT) {
+        const int row = i / kOutCap, k = i % kOutCap;
+        const int4 sp = x.span[row];
+        if (sp.z + k < sp.w) {
+            const int c = a.out_dst[sp.z + k], sl = a.out_slot[sp.z + k];
+            const uint8_t gc = a.gslot[c];
+            float al = 0.f, ds = 0.f;
+            if (gc != kNoGateX) { al = a.alpha[sl]; ds = a.dsc[sl]; }
+            o.c[i] = c; o.al[i] = al; o.ds[i] = ds; o.gc[i] = gc;
+        }
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain every outstanding global
+// load, store and atomic (vmcnt(0)), and these kernels exchange nothing through global memory inside a tile.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ float4 f4(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
+
+// source rows of a node's first kInRegs in-edges, loaded together into registers the untaken path never writes
 template <int H>
-__device__ __forceinline__ void attn_row_x(const LevelX3Args& a, int64_t node, const float4& us, const float4& uf, int lr,
-                                           float& m, float& inv, float4& zs, float4& zf) {
+struct InRows {
+    f32x4 xs[kInRegs], xf[kInRegs];
+    __device__ __forceinline__ void issue(const LevelX3Args& a, const int* insrc_row, int deg, int lr) {
+#pragma unroll
+        for (int k = 0; k < kInRegs; ++k)
+            if (k < deg) {
+                const int64_t j = insrc_row[k];
+                xs[k] = *reinterpret_cast<const f32x4*>(a.hs + j * H + 4 * lr);
+                xf[k] = *reinterpret_cast<const f32x4*>(a.hf + j * H + 4 * lr);
+            }
+    }
+};
+
+// softmax attention over the in-edges (online form, same operation order as func_level.hip)
+template <int H>
+__device__ __forceinline__ void attn_reduce(const LevelX3Args& a, const InRows<H>& L, const int4& sp, const float4& us,
+                                            const float4& uf, int lr, float& m, float& inv, float4& zs, float4& zf) {
     constexpr int LPR = H / 4;
-    const int e0 = a.in_ptr[node], e1 = a.in_ptr[node + 1];
+    const int deg = sp.y - sp.x;
     m = -INFINITY;
     float S = 0.f;
     zs = zero4(); zf = zero4();
-    for (int e = e0; e < e1; ++e) {
+#pragma unroll
+    for (int k = 0; k < kInRegs; ++k)
+        if (k < deg) {
+            const float4 xs = f4(L.xs[k]), xf = f4(L.xf[k]);
+            const float sc = group_sum<LPR>(dot4(us, xs) + dot4(uf, xf));
+            const float mn = fmaxf(m, sc);
+            const float corr = __expf(m - mn), w = __expf(sc - mn);
+            S = S * corr + w;
+            zs = fma4(w, xs, scale4(corr, zs));
+            zf = fma4(w, xf, scale4(corr, zf));
+            m = mn;
+        }
+    for (int e = sp.x + kInRegs; e < sp.y; ++e) {
         const int64_t j = a.in_src[e];
         const float4 xs = ld4(a.hs + j * H + 4 * lr), xf = ld4(a.hf + j * H + 4 * lr);
         const float sc = group_sum<LPR>(dot4(us, xs) + dot4(uf, xf));
@@ -85,34 +217,26 @@ __device__ __forceinline__ void attn_row_x(const LevelX3Args& a, int64_t node, c
         zf = fma4(w, xf, scale4(corr, zf));
         m = mn;
     }
-    inv = 1.0f / (S + 1e-16f);
+    inv = 1.0f / (S + 1e-16f);       // torch_geometric softmax: e / (sum e + 1e-16)
     zs = scale4(inv, zs); zf = scale4(inv, zf);
-    if (e1 == e0) m = 0.f;
+    if (deg <= 0) m = 0.f;
 }
 
 template <int H>
-__device__ __forceinline__ void pull_row_x(const LevelX3Args& a, int64_t node, int lr, float4& gs, float4& gf) {
-    const int e0 = a.out_ptr[node], e1 = a.out_ptr[node + 1];
-    gs = zero4(); gf = zero4();
-    for (int e = e0; e < e1; ++e) {
-        const int64_t c = a.out_dst[e];
-        const int gc = a.gslot[c];
-        if (gc == kNoGateX) continue;
-        const int sl = a.out_slot[e];
-        const float al = a.alpha[sl], ds = a.dsc[sl];
-        const float* dz = a.dzb + c * 2 * H;
-        const float* u = a.attn_u + (int64_t)gc * 2 * H;
-        gs = fma4(al, ld4(dz + 4 * lr), fma4(ds, ld4(u + 4 * lr), gs));
-        gf = fma4(al, ld4(dz + H + 4 * lr), fma4(ds, ld4(u + H + 4 * lr), gf));
-    }
+__device__ __forceinline__ void store_zbar(__bf16* z_hi, __bf16* z_lo, int row, int lr, const float4& zs, const float4& zf) {
+    constexpr int LDZP = 2 * H + 8;
+    bf16x4 hi, lo;
+    split4(zs, hi, lo);
+    st_bf4(z_hi + row * LDZP + 4 * lr, hi); st_bf4(z_lo + row * LDZP + 4 * lr, lo);
+    split4(zf, hi, lo);
+    st_bf4(z_hi + row * LDZP + H + 4 * lr, hi); st_bf4(z_lo + row * LDZP + H + 4 * lr, lo);
 }
 
 // gate pre-activations (r, z, n blocks) = zbar[64 x 2H] * Wvc_g^T from the split planes
 template <int H>
 __device__ __forceinline__ void lvl_gemm_x3(const __bf16* wslot, const __bf16* z_hi, const __bf16* z_lo,
-                                            f32x4 (&ar)[WaveSplit<H>::RTW], f32x4 (&az)[WaveSplit<H>::RTW], f32x4 (&an)[WaveSplit<H>::RTW]) {
-    using S = WaveSplit<H>;
-    static_assert(S::HCW == 1, "one hidden-column tile per wave");
+                                            f32x4 (&ar)[SplitL<H>::RTW], f32x4 (&az)[SplitL<H>::RTW], f32x4 (&an)[SplitL<H>::RTW]) {
+    using S = SplitL<H>;
     constexpr int LDZP = 2 * H + 8, BLK = 6 * H * H, KS = 2 * H / 32;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
     const int wc = w % S::WPC, wr = w / S::WPC;
@@ -141,43 +265,49 @@ __device__ __forceinline__ void lvl_gemm_x3(const __bf16* wslot, const __bf16* z
 }
 
 template <int H>
-__global__ __launch_bounds__(kThreads) void k_level_fwd_x3(LevelX3Args a) {
-    using S = WaveSplit<H>;
+__global__ __launch_bounds__(kLT, 4) void k_level_fwd_x3(LevelX3Args a) {
+    using S = SplitL<H>;
     using M = LvlSmem<H>;
-    constexpr int LDZP = M::LDZP;
+    constexpr int LPR = M::LPR, GROUPS = M::GROUPS, RPG = M::RPG, LDO = M::LDO;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* z_hi = reinterpret_cast<__bf16*>(smem_raw + M::o_zhi);
     __bf16* z_lo = reinterpret_cast<__bf16*>(smem_raw + M::o_zlo);
     float* s_o = reinterpret_cast<float*>(smem_raw + M::o_zhi);       // output tile, after the MFMAs
+    const LvlIdx ix = lvl_idx(smem_raw + M::o_idx_f);
     const int tile = a.tile_begin + blockIdx.x;
     const int start = a.tile_start[tile], count = a.tile_count[tile], g = a.tile_slot[tile];
+    stage_spans(a, start, count, ix);
     const LvlSmall sv = lvl_small<H>(a, g, reinterpret_cast<float*>(smem_raw + M::o_small_f));
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wc = w % S::WPC, wr = w / S::WPC;
-    const int grp = tid / S::LPR, lr = tid % S::LPR;
-    __syncthreads();
+    const int grp = tid / LPR, lr = tid % LPR;
+    lds_barrier();
+    stage_in_edges(a, ix);
+    lds_barrier();
     const float4 us = ld4(sv.u + 4 * lr), uf = ld4(sv.u + H + 4 * lr);
-    for (int row = grp; row < kTileRows; row += S::GROUPS) {
-        float4 zs = zero4(), zf = zero4();
-        float sa = 0.f;
-        int node = -1;
-        if (row < count) {
-            node = a.order[start + row];
-            float m, inv;
-            attn_row_x<H>(a, node, us, uf, lr, m, inv, zs, zf);
-            sa = a.in_ptr[node + 1] > a.in_ptr[node] ? 1.0f : 0.0f;
+    {
+        InRows<H> L[RPG];
+        int4 sp[RPG];
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            const int row = grp + i * GROUPS;
+            sp[i] = ix.span[row];
+            L[i].issue(a, ix.insrc + row * kInCap, sp[i].y - sp[i].x, lr);
         }
-        bf16x4 hi, lo;
-        split4(zs, hi, lo);
-        st_bf4(z_hi + row * LDZP + 4 * lr, hi); st_bf4(z_lo + row * LDZP + 4 * lr, lo);
-        split4(zf, hi, lo);
-        st_bf4(z_hi + row * LDZP + H + 4 * lr, hi); st_bf4(z_lo + row * LDZP + H + 4 * lr, lo);
-        if (lr == 0) { sv.sa[row] = sa; sv.node[row] = node; }
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            const int row = grp + i * GROUPS;
+            float m, inv;
+            float4 zs, zf;
+            attn_reduce<H>(a, L[i], sp[i], us, uf, lr, m, inv, zs, zf);
+            store_zbar<H>(z_hi, z_lo, row, lr, zs, zf);
+            if (lr == 0) sv.sa[row] = sp[i].y > sp[i].x ? 1.0f : 0.0f;
+        }
     }
-    __syncthreads();
+    lds_barrier();
     f32x4 ar[S::RTW], az[S::RTW], an[S::RTW];
     lvl_gemm_x3<H>(a.wpack + (int64_t)g * 4 * 6 * H * H, z_hi, z_lo, ar, az, an);
-    __syncthreads();                   // s_o overlays the planes
+    lds_barrier();                   // s_o overlays the planes
     {
         const int col = wc * 16 + r;
         const float bvr = sv.bvc[col], bvz = sv.bvc[H + col], bvn = sv.bvc[2 * H + col];
@@ -192,12 +322,15 @@ __global__ __launch_bounds__(kThreads) void k_level_fwd_x3(LevelX3Args a) {
                 const float rr = sigmoidf_(ar[i][e] + sa * bvr + cr);
                 const float zz = sigmoidf_(az[i][e] + sa * bvz + cz);
                 const float nn = tanhf_(an[i][e] + sa * bvn + cn + rr * bhn);
-                s_o[row * S::LD + col] = (1.0f - zz) * nn;        // h0 = 0
+                s_o[row * LDO + col] = (1.0f - zz) * nn;        // h0 = 0
             }
     }
-    __syncthreads();
-    for (int row = grp; row < count; row += S::GROUPS)
-        st4(a.hf + (int64_t)sv.node[row] * H + 4 * lr, ld4(s_o + row * S::LD + 4 * lr));
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < RPG; ++i) {
+        const int row = grp + i * GROUPS;
+        if (row < count) st4(a.hf + (int64_t)ix.node[row] * H + 4 * lr, ld4(s_o + row * LDO + 4 * lr));
+    }
 }
 
 __device__ __forceinline__ void colsum_lds_lx(float v, float* dst) {
@@ -206,14 +339,92 @@ __device__ __forceinline__ void colsum_lds_lx(float v, float* dst) {
     if ((threadIdx.x & 63) < 16) atomicAdd(dst, v);
 }
 
+// gradient a node's rows receive from its consumers' attention inputs, consumers beyond the staged list
 template <int H>
-__global__ __launch_bounds__(kThreads) void k_level_bwd_x3(LevelX3Args a) {
-    using S = WaveSplit<H>;
-    using S2 = WaveSplit<2 * H>;
+__device__ __forceinline__ void pull_tail(const LevelX3Args& a, int e0, int e1, int lr, float4& gs, float4& gf) {
+    for (int e = e0; e < e1; ++e) {
+        const int64_t c = a.out_dst[e];
+        const int gc = a.gslot[c];
+        if (gc == kNoGateX) continue;
+        const int sl = a.out_slot[e];
+        const float al = a.alpha[sl], ds = a.dsc[sl];
+        const float* dz = a.dzb + c * 2 * H;
+        const float* u = a.attn_u + (int64_t)gc * 2 * H;
+        gs = fma4(al, ld4(dz + 4 * lr), fma4(ds, ld4(u + 4 * lr), gs));
+        gf = fma4(al, ld4(dz + H + 4 * lr), fma4(ds, ld4(u + H + 4 * lr), gf));
+    }
+}
+
+// consumers [k0, k0 + kOutChunk) of the staged list: their d(zbar) rows loaded together
+template <int H>
+struct OutRows {
+    f32x4 ds_[kOutChunk], df_[kOutChunk];
+    __device__ __forceinline__ void issue(const LevelX3Args& a, const OutStage& o, int base, int k0, int n, int lr) {
+#pragma unroll
+        for (int k = 0; k < kOutChunk; ++k)
+            if (k0 + k < n && o.gc[base + k0 + k] != kNoGateX) {
+                const float* dz = a.dzb + (int64_t)o.c[base + k0 + k] * 2 * H;
+                ds_[k] = *reinterpret_cast<const f32x4*>(dz + 4 * lr);
+                df_[k] = *reinterpret_cast<const f32x4*>(dz + H + 4 * lr);
+            }
+    }
+    __device__ __forceinline__ void reduce(const OutStage& o, const float* uall, int base, int k0, int n, int lr, float4& gs, float4& gf) const {
+#pragma unroll
+        for (int k = 0; k < kOutChunk; ++k)
+            if (k0 + k < n && o.gc[base + k0 + k] != kNoGateX) {
+                const float al = o.al[base + k0 + k], ds = o.ds[base + k0 + k];
+                const float* u = uall + (int)o.gc[base + k0 + k] * 2 * H;
+                gs = fma4(al, f4(ds_[k]), fma4(ds, ld4(u + 4 * lr), gs));
+                gf = fma4(al, f4(df_[k]), fma4(ds, ld4(u + H + 4 * lr), gf));
+            }
+    }
+};
+
+// attention backward of one row from its staged source rows: alpha and d(score) of the first kInRegs in-edges come
+// back in registers (the caller stores them after it has issued the next row's loads); longer lists finish here
+template <int H>
+__device__ __forceinline__ void attn_bwd_row(const LevelX3Args& a, const InRows<H>& L, const int4& sp, const float4& us,
+                                             const float4& uf, const float4& dzs, const float4& dzf, float ci, float m,
+                                             float inv, int lr, float (&al)[kInRegs], float (&ds)[kInRegs], float4& gus, float4& guf) {
+    constexpr int LPR = H / 4;
+    const int deg = sp.y - sp.x;
+#pragma unroll
+    for (int k = 0; k < kInRegs; ++k)
+        if (k < deg) {
+            const float4 xs = f4(L.xs[k]), xf = f4(L.xf[k]);
+            const float sc = group_sum<LPR>(dot4(us, xs) + dot4(uf, xf));
+            const float t = group_sum<LPR>(dot4(dzs, xs) + dot4(dzf, xf));
+            al[k] = __expf(sc - m) * inv;
+            ds[k] = al[k] * (t - ci);
+            gus = fma4(ds[k], xs, gus);
+            guf = fma4(ds[k], xf, guf);
+        }
+    for (int e = sp.x + kInRegs; e < sp.y; ++e) {
+        const int64_t j = a.in_src[e];
+        const float4 xs = ld4(a.hs + j * H + 4 * lr), xf = ld4(a.hf + j * H + 4 * lr);
+        const float sc = group_sum<LPR>(dot4(us, xs) + dot4(uf, xf));
+        const float t = group_sum<LPR>(dot4(dzs, xs) + dot4(dzf, xf));
+        const float al_e = __expf(sc - m) * inv;
+        const float ds_e = al_e * (t - ci);
+        if (lr == 0) { a.alpha[e] = al_e; a.dsc[e] = ds_e; }
+        gus = fma4(ds_e, xs, gus);
+        guf = fma4(ds_e, xf, guf);
+    }
+}
+
+// Backward of one tile.  Global memory discipline: a wave's loads wait for every older load, store or atomic of
+// that wave (vmcnt is in order), so nothing is stored before the tile's last load has been issued; per-tile float
+// atomics are out (memory-side, ~1.3 TB/s chip-wide, 14x slower when every workgroup adds to the same rows).  The
+// weight gradient is therefore not formed here: the tile leaves its gate gradients dG[pos][3H] and its zbar rows
+// z[pos][2H] (pos = position in `order`) for k_sweep_wgrad_x3, and adds its small parameter gradients (gu, dbvc,
+// dbih, dbhh) with plain loads/stores into the slab that workgroup b of EVERY level owns per slot.
+template <int H>
+__global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
+    using S = SplitL<H>;
+    using S2 = SplitL<2 * H>;
     using M = LvlSmem<H>;
+    constexpr int LPR = M::LPR, GROUPS = M::GROUPS, RPG = M::RPG, LDO = M::LDO;
     constexpr int LDZP = M::LDZP, LDGP = M::LDGP, LDZF = M::LDZF, BLK = 6 * H * H;
-    constexpr int TI = H / 16, TJ = 2 * H / 16, TT = TI * TJ, TPW = TT / 4;
-    static_assert(TT % 4 == 0, "wgrad tiles must split over 4 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* z_hi = reinterpret_cast<__bf16*>(smem_raw + M::o_zhi);
     __bf16* z_lo = reinterpret_cast<__bf16*>(smem_raw + M::o_zlo);
@@ -221,45 +432,69 @@ __global__ __launch_bounds__(kThreads) void k_level_bwd_x3(LevelX3Args a) {
     __bf16* d_hi = reinterpret_cast<__bf16*>(smem_raw + M::o_r);
     __bf16* d_lo = d_hi + kTileRows * LDGP;
     float* s_dz = reinterpret_cast<float*>(smem_raw + M::o_r);
+    const OutStage os = out_stage(smem_raw + M::o_out);
+    const LvlIdx ix = lvl_idx(smem_raw + M::o_idx_b);
     const int tile = a.tile_begin + blockIdx.x;
+    STAMP_DECL
+    STAMP_BEGIN;
     const int start = a.tile_start[tile], count = a.tile_count[tile], g = a.tile_slot[tile];
+    stage_spans(a, start, count, ix);
     const LvlSmall sv = lvl_small<H>(a, g, reinterpret_cast<float*>(smem_raw + M::o_small_b));
     float* s_gu = reinterpret_cast<float*>(smem_raw + M::o_acc);
     float* s_dbvc = s_gu + 2 * H; float* s_dbih = s_dbvc + 3 * H; float* s_dbhh = s_dbih + 3 * H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wc = w % S::WPC, wr = w / S::WPC;
-    const int grp = tid / S::LPR, lr = tid % S::LPR;
-    for (int i = tid; i < 2 * H + 9 * H; i += kThreads) s_gu[i] = 0.f;
-    __syncthreads();
+    const int grp = tid / LPR, lr = tid % LPR;
+    float* slab_small = a.wslab + ((int64_t)blockIdx.x * a.T + g) * (11 * H);
+    for (int i = tid; i < 11 * H; i += kLT) s_gu[i] = slab_small[i];
+    lds_barrier();
+    STAMP(0);
+    stage_in_edges(a, ix);
+    stage_out_edges(a, ix, os);
+    lds_barrier();
+    STAMP(1);
     const float4 us = ld4(sv.u + 4 * lr), uf = ld4(sv.u + H + 4 * lr);
-    // ---- 0/1. pull dL/dhf (and finish dL/dhs) of the tile's nodes, recompute their attention
-    for (int row = grp; row < kTileRows; row += S::GROUPS) {
-        float4 zs = zero4(), zf = zero4(), dh = zero4();
-        float sa = 0.f, m = 0.f, inv = 0.f;
-        int node = -1;
-        if (row < count) {
-            node = a.order[start + row];
-            float4 gs, gf;
-            pull_row_x<H>(a, node, lr, gs, gf);
-            dh = add4(gf, ld4(a.ghf + (int64_t)node * H + 4 * lr));
-            float* gp = a.ghs + (int64_t)node * H + 4 * lr;
-            st4(gp, add4(ld4(gp), gs));
-            attn_row_x<H>(a, node, us, uf, lr, m, inv, zs, zf);
-            sa = a.in_ptr[node + 1] > a.in_ptr[node] ? 1.0f : 0.0f;
+    // ---- 0/1. pull dL/dhf and dL/dhs of the tile's nodes from their consumers, recompute their attention
+    float4 gs_keep[2] = {zero4(), zero4()};      // dL/dhs rows, stored at the end
+    static_assert(RPG <= 2, "two kept rows");
+#pragma unroll 1
+    for (int i = 0; i < RPG; ++i) {
+        const int row = grp + i * GROUPS;
+        const int4 sp = ix.span[row];
+        const int node = ix.node[row];
+        const int nout = min(sp.w - sp.z, kOutCap);
+        InRows<H> L;
+        OutRows<H> P;
+        f32x4 own;
+        L.issue(a, ix.insrc + row * kInCap, sp.y - sp.x, lr);
+        P.issue(a, os, row * kOutCap, 0, nout, lr);
+        if (node >= 0) own = *reinterpret_cast<const f32x4*>(a.ghf + (int64_t)node * H + 4 * lr);
+        float4 gs = zero4(), gf = zero4();
+        P.reduce(os, sv.uall, row * kOutCap, 0, nout, lr, gs, gf);
+        for (int k0 = kOutChunk; k0 < nout; k0 += kOutChunk) {
+            OutRows<H> Q;
+            Q.issue(a, os, row * kOutCap, k0, nout, lr);
+            Q.reduce(os, sv.uall, row * kOutCap, k0, nout, lr, gs, gf);
         }
-        bf16x4 hi, lo;
-        split4(zs, hi, lo);
-        st_bf4(z_hi + row * LDZP + 4 * lr, hi); st_bf4(z_lo + row * LDZP + 4 * lr, lo);
-        split4(zf, hi, lo);
-        st_bf4(z_hi + row * LDZP + H + 4 * lr, hi); st_bf4(z_lo + row * LDZP + H + 4 * lr, lo);
-        st4(s_dh + row * S::LD + 4 * lr, dh);
-        if (lr == 0) { sv.sa[row] = sa; sv.m[row] = m; sv.inv[row] = inv; sv.node[row] = node; }
+        pull_tail<H>(a, sp.z + kOutCap, sp.w, lr, gs, gf);
+        float4 dh = zero4();
+        if (node >= 0) dh = add4(gf, f4(own));
+        if (i == 0) gs_keep[0] = gs; else gs_keep[1] = gs;
+        float m, inv;
+        float4 zs, zf;
+        attn_reduce<H>(a, L, sp, us, uf, lr, m, inv, zs, zf);
+        store_zbar<H>(z_hi, z_lo, row, lr, zs, zf);
+        st4(s_dh + row * LDO + 4 * lr, dh);
+        if (lr == 0) { sv.sa[row] = sp.y > sp.x ? 1.0f : 0.0f; sv.m[row] = m; sv.inv[row] = inv; }
     }
-    __syncthreads();
+    STAMP(2);
+    lds_barrier();
+    STAMP(3);
     // ---- 2. recompute gates
     const __bf16* wslot = a.wpack + (int64_t)g * 4 * BLK;
     f32x4 ar[S::RTW], az[S::RTW], an[S::RTW];
     lvl_gemm_x3<H>(wslot, z_hi, z_lo, ar, az, an);
+    STAMP(4);
     // ---- 3. GRU backward (h0 = 0: hf = (1-z) n, gh = b_hh); ar/az/an become da_r/da_z/da_n
     {
         const int col = wc * 16 + r;
@@ -276,7 +511,7 @@ __global__ __launch_bounds__(kThreads) void k_level_bwd_x3(LevelX3Args a) {
                 const float rr = sigmoidf_(ar[i][e] + sa * bvr + cr);
                 const float zz = sigmoidf_(az[i][e] + sa * bvz + cz);
                 const float nn = tanhf_(an[i][e] + sa * bvn + cn + rr * bhn);
-                const float dh = s_dh[row * S::LD + col];
+                const float dh = s_dh[row * LDO + col];
                 const float dan = dh * (1.0f - zz) * (1.0f - nn * nn);
                 const float daz = -dh * nn * zz * (1.0f - zz);
                 const float dar = dan * bhn * rr * (1.0f - rr);
@@ -288,17 +523,22 @@ __global__ __launch_bounds__(kThreads) void k_level_bwd_x3(LevelX3Args a) {
         colsum_lds_lx(b_r, s_dbhh + col); colsum_lds_lx(b_z, s_dbhh + H + col); colsum_lds_lx(h_n, s_dbhh + 2 * H + col);
         colsum_lds_lx(v_r, s_dbvc + col); colsum_lds_lx(v_z, s_dbvc + H + col); colsum_lds_lx(v_n, s_dbvc + 2 * H + col);
     }
-    // ---- 4. three passes: d(zbar) += dG_p * Wvc[p]  and  dWvc[p] += dG_p^T * zbar
+    STAMP(5);
+    // ---- 4. three passes: d(zbar) += dG_p * Wvc[p]
     const int wc2 = w % S2::WPC, wr2 = w / S2::WPC;
-    f32x4 dz[S2::RTW][S2::HCW];
+    f32x4 dz[S2::RTW];
 #pragma unroll
-    for (int i = 0; i < S2::RTW; ++i)
-#pragma unroll
-        for (int j = 0; j < S2::HCW; ++j) dz[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float* dWvc_g = a.dWvc + (int64_t)g * 3 * H * 2 * H;
+    for (int i = 0; i < S2::RTW; ++i) dz[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        __syncthreads();               // readers of region R: phase 3 (dh), or the previous pass
+        // B operands of this pass: issued before the barriers, their latency hides behind the plane writes
+        bf16x8 bh[H / 32], bl[H / 32];
+#pragma unroll
+        for (int ks = 0; ks < H / 32; ++ks) {
+            const int wo = ((wc2 * 3 + p) * (H / 32) + ks) * 512 + lane * 8;
+            bh[ks] = ldfrag(wslot + 2 * BLK + wo); bl[ks] = ldfrag(wslot + 3 * BLK + wo);
+        }
+        lds_barrier();                 // readers of region R: phase 3 (dh), or the previous pass
         {
             const int col = wc * 16 + r;
 #pragma unroll
@@ -312,87 +552,91 @@ __global__ __launch_bounds__(kThreads) void k_level_bwd_x3(LevelX3Args a) {
                     d_hi[row * LDGP + col] = hh; d_lo[row * LDGP + col] = ll;
                 }
         }
-        __syncthreads();
-#pragma unroll 1
-        for (int ks = 0; ks < H / 32; ++ks) {
-            bf16x8 xh[S2::RTW], xl[S2::RTW];
+        lds_barrier();
+        STAMP(6);
+#pragma unroll
+        for (int ks = 0; ks < H / 32; ++ks)
 #pragma unroll
             for (int i = 0; i < S2::RTW; ++i) {
                 const int off = ((wr2 * S2::RTW + i) * 16 + r) * LDGP + 32 * ks + 8 * q;
-                xh[i] = ldfrag(d_hi + off); xl[i] = ldfrag(d_lo + off);
+                mma_x3(dz[i], ldfrag(d_hi + off), ldfrag(d_lo + off), bh[ks], bl[ks]);
             }
-#pragma unroll
-            for (int j = 0; j < S2::HCW; ++j) {
-                const int ct2 = wc2 * S2::HCW + j;
-                const int wo = ((ct2 * 3 + p) * (H / 32) + ks) * 512 + lane * 8;
-                const bf16x8 bh = ldfrag(wslot + 2 * BLK + wo), bl = ldfrag(wslot + 3 * BLK + wo);
-#pragma unroll
-                for (int i = 0; i < S2::RTW; ++i) mma_x3(dz[i][j], xh[i], xl[i], bh, bl);
-            }
-        }
-        // weight gradient of this gate block: both operands read transposed from the row-major planes
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-            const int tl = w * TPW + t;
-            const int it = tl / TJ, jt = tl % TJ;
-            f32x4 gw = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < kTileRows / 32; ++ks)
-                mma_x3(gw, ldfrag_tr(d_hi, LDGP, 32 * ks, it * 16), ldfrag_tr(d_lo, LDGP, 32 * ks, it * 16),
-                       ldfrag_tr(z_hi, LDZP, 32 * ks, jt * 16), ldfrag_tr(z_lo, LDZP, 32 * ks, jt * 16));
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                atomicAdd(dWvc_g + (int64_t)(p * H + it * 16 + q * 4 + e) * 2 * H + jt * 16 + r, gw[e]);
-        }
+        STAMP(7);
     }
     // ---- 5. d(zbar) tile to LDS (fp32, row layout for the attention backward); it overlays the dG planes
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
-    for (int i = 0; i < S2::RTW; ++i)
+    for (int i = 0; i < S2::RTW; ++i) {
+        const int col = wc2 * 16 + r;
 #pragma unroll
-        for (int j = 0; j < S2::HCW; ++j) {
-            const int col = (wc2 * S2::HCW + j) * 16 + r;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s_dz[((wr2 * S2::RTW + i) * 16 + q * 4 + e) * LDZF + col] = dz[i][j][e];
-        }
-    __syncthreads();
-    // ---- 6. attention backward per in-edge
+        for (int e = 0; e < 4; ++e) s_dz[((wr2 * S2::RTW + i) * 16 + q * 4 + e) * LDZF + col] = dz[i][e];
+    }
+    lds_barrier();
+    STAMP(9);
+    // ---- 6. attention backward per in-edge: leave alpha, d(score) for the sources' pulls, d(zbar) per node.
+    // A row's stores are issued after the next row's loads.
     float4 gus = zero4(), guf = zero4();
-    for (int row = grp; row < count; row += S::GROUPS) {
-        const int64_t node = sv.node[row];
-        const float4 dzs = ld4(s_dz + row * LDZF + 4 * lr), dzf = ld4(s_dz + row * LDZF + H + 4 * lr);
-        const bf16x4 zsh = *reinterpret_cast<const bf16x4*>(z_hi + row * LDZP + 4 * lr), zsl = *reinterpret_cast<const bf16x4*>(z_lo + row * LDZP + 4 * lr);
-        const bf16x4 zfh = *reinterpret_cast<const bf16x4*>(z_hi + row * LDZP + H + 4 * lr), zfl = *reinterpret_cast<const bf16x4*>(z_lo + row * LDZP + H + 4 * lr);
-        const float4 zs = make_float4((float)zsh[0] + (float)zsl[0], (float)zsh[1] + (float)zsl[1], (float)zsh[2] + (float)zsl[2], (float)zsh[3] + (float)zsl[3]);
-        const float4 zf = make_float4((float)zfh[0] + (float)zfl[0], (float)zfh[1] + (float)zfl[1], (float)zfh[2] + (float)zfl[2], (float)zfh[3] + (float)zfl[3]);
-        st4(a.dzb + node * 2 * H + 4 * lr, dzs);
-        st4(a.dzb + node * 2 * H + H + 4 * lr, dzf);
-        const float ci = group_sum<S::LPR>(dot4(dzs, zs) + dot4(dzf, zf));
-        const float m = sv.m[row], inv = sv.inv[row];
-        const int e0 = a.in_ptr[node], e1 = a.in_ptr[node + 1];
-        for (int e = e0; e < e1; ++e) {
-            const int64_t j = a.in_src[e];
-            const float4 xs = ld4(a.hs + j * H + 4 * lr), xf = ld4(a.hf + j * H + 4 * lr);
-            const float sc = group_sum<S::LPR>(dot4(us, xs) + dot4(uf, xf));
-            const float t = group_sum<S::LPR>(dot4(dzs, xs) + dot4(dzf, xf));
-            const float al = __expf(sc - m) * inv;
-            const float ds = al * (t - ci);
-            if (lr == 0) { a.alpha[e] = al; a.dsc[e] = ds; }
-            gus = fma4(ds, xs, gus);
-            guf = fma4(ds, xf, guf);
+    {
+        InRows<H> L[RPG];
+        int4 sp[RPG];
+        float al[RPG][kInRegs], ds[RPG][kInRegs];
+        sp[0] = ix.span[grp];
+        L[0].issue(a, ix.insrc + grp * kInCap, sp[0].y - sp[0].x, lr);
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            const int row = grp + i * GROUPS;
+            const float4 dzs = ld4(s_dz + row * LDZF + 4 * lr), dzf = ld4(s_dz + row * LDZF + H + 4 * lr);
+            const bf16x4 zsh = *reinterpret_cast<const bf16x4*>(z_hi + row * LDZP + 4 * lr), zsl = *reinterpret_cast<const bf16x4*>(z_lo + row * LDZP + 4 * lr);
+            const bf16x4 zfh = *reinterpret_cast<const bf16x4*>(z_hi + row * LDZP + H + 4 * lr), zfl = *reinterpret_cast<const bf16x4*>(z_lo + row * LDZP + H + 4 * lr);
+            const float4 zs = make_float4((float)zsh[0] + (float)zsl[0], (float)zsh[1] + (float)zsl[1], (float)zsh[2] + (float)zsl[2], (float)zsh[3] + (float)zsl[3]);
+            const float4 zf = make_float4((float)zfh[0] + (float)zfl[0], (float)zfh[1] + (float)zfl[1], (float)zfh[2] + (float)zfl[2], (float)zfh[3] + (float)zfl[3]);
+            const float ci = group_sum<LPR>(dot4(dzs, zs) + dot4(dzf, zf));
+            if (row < count) attn_bwd_row<H>(a, L[i], sp[i], us, uf, dzs, dzf, ci, sv.m[row], sv.inv[row], lr, al[i], ds[i], gus, guf);
+            if (i + 1 < RPG) {
+                sp[i + 1] = ix.span[row + GROUPS];
+                L[i + 1].issue(a, ix.insrc + (row + GROUPS) * kInCap, sp[i + 1].y - sp[i + 1].x, lr);
+            }
+            if (row < count) {
+                const int64_t node = ix.node[row];
+                const int64_t pos = start + row;
+                st4(a.dzb + node * 2 * H + 4 * lr, dzs);
+                st4(a.dzb + node * 2 * H + H + 4 * lr, dzf);
+                st4(a.zrows + pos * 2 * H + 4 * lr, zs);
+                st4(a.zrows + pos * 2 * H + H + 4 * lr, zf);
+                st4(a.ghs + node * H + 4 * lr, gs_keep[i]);
+                const int deg = sp[i].y - sp[i].x;
+                if (lr == 0) {
+#pragma unroll
+                    for (int k = 0; k < kInRegs; ++k)
+                        if (k < deg) { a.alpha[sp[i].x + k] = al[i][k]; a.dsc[sp[i].x + k] = ds[i][k]; }
+                }
+            }
         }
+    }
+    STAMP(10);
+    // gate gradients of the tile's rows, for the weight-gradient kernel
+    {
+        const int col = wc * 16 + r;
+#pragma unroll
+        for (int i = 0; i < S::RTW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
+                if (row < count) {
+                    float* dg = a.dgrows + (int64_t)(start + row) * 3 * H + col;
+                    dg[0] = ar[i][e]; dg[H] = az[i][e]; dg[2 * H] = an[i][e];
+                }
+            }
     }
     atomicAdd(&s_gu[4 * lr + 0], gus.x); atomicAdd(&s_gu[4 * lr + 1], gus.y); atomicAdd(&s_gu[4 * lr + 2], gus.z); atomicAdd(&s_gu[4 * lr + 3], gus.w);
     atomicAdd(&s_gu[H + 4 * lr + 0], guf.x); atomicAdd(&s_gu[H + 4 * lr + 1], guf.y); atomicAdd(&s_gu[H + 4 * lr + 2], guf.z); atomicAdd(&s_gu[H + 4 * lr + 3], guf.w);
-    __syncthreads();
-    for (int i = tid; i < 2 * H; i += kThreads) atomicAdd(a.d_attn_u + (int64_t)g * 2 * H + i, s_gu[i]);
-    for (int i = tid; i < 3 * H; i += kThreads) {
-        atomicAdd(a.dbvc + (int64_t)g * 3 * H + i, s_dbvc[i]);
-        atomicAdd(a.dbih + (int64_t)g * 3 * H + i, s_dbih[i]);
-        atomicAdd(a.dbhh + (int64_t)g * 3 * H + i, s_dbhh[i]);
-    }
+    lds_barrier();
+    for (int i = tid; i < 11 * H; i += kLT) slab_small[i] = s_gu[i];
+    STAMP(11);
+    STAMP_FLUSH(a);
 }
 
+// nodes the sweep never updates (primary inputs, unknown gate types): only their hs rows feed consumers
 template <int H>
 __global__ __launch_bounds__(kThreads) void k_level_pull_inactive_x3(LevelX3Args a) {
     constexpr int LPR = H / 4;
@@ -400,10 +644,118 @@ __global__ __launch_bounds__(kThreads) void k_level_pull_inactive_x3(LevelX3Args
     const int64_t stride = (int64_t)gridDim.x * (kThreads / LPR);
     for (int64_t node = (int64_t)blockIdx.x * (kThreads / LPR) + threadIdx.x / LPR; node < a.N; node += stride) {
         if (a.gslot[node] != kNoGateX) continue;
-        float4 gs, gf;
-        pull_row_x<H>(a, node, lr, gs, gf);
-        float* gp = a.ghs + node * H + 4 * lr;
-        st4(gp, add4(ld4(gp), gs));
+        float4 gs = zero4(), gf = zero4();
+        pull_tail<H>(a, a.out_ptr[node], a.out_ptr[node + 1], lr, gs, gf);
+        st4(a.ghs + node * H + 4 * lr, gs);
+    }
+}
+
+// dWvc[g] += sum over the rows of slot g of dG[row]^T zbar[row], from the rows the level kernels left behind.
+// Persistent workgroups walk the slot's tile list; a tile's fp32 rows are split into bf16 hi/lo planes in LDS
+// and both MFMA operands are read transposed from them; the next tile's rows are in flight (registers) meanwhile.
+template <int H>
+struct WgradGeom {
+    static constexpr int NW = H >= 64 ? 16 : 8;               // waves
+    static constexpr int NT = 64 * NW;
+    static constexpr int TI = 3 * H / 16, TJ = 2 * H / 16;    // 16x16 output tiles
+    static constexpr int ITW = 3, JTW = TJ / 4;               // per wave: 3 x JTW tiles; 4 wave groups across TJ
+    static_assert(TI / ITW * 4 == NW && JTW >= 1, "wave grid must cover the output");
+    static constexpr int LDG = 3 * H + 8, LDZ = 2 * H + 8;    // bf16 plane rows
+    static constexpr int GPB = kTileRows * LDG * 2, ZPB = kTileRows * LDZ * 2;
+    static constexpr int smem_bytes = 2 * GPB + 2 * ZPB;
+    static constexpr int F4G = kTileRows * 3 * H / 4, F4Z = kTileRows * 2 * H / 4;
+    static constexpr int PF = (F4G + F4Z) / NT;               // float4 loads per thread per tile
+    static_assert(PF * NT == F4G + F4Z, "row loads must split evenly");
+};
+
+template <int H>
+__global__ __launch_bounds__(WgradGeom<H>::NT) void k_sweep_wgrad_x3(const float* dgrows, const float* zrows, const int32_t* tile_list,
+                                                                     int ntiles, const int32_t* tile_start, const int32_t* tile_count,
+                                                                     float* dW) {
+    using G = WgradGeom<H>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* g_hi = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* g_lo = reinterpret_cast<__bf16*>(smem_raw + G::GPB);
+    __bf16* z_hi = reinterpret_cast<__bf16*>(smem_raw + 2 * G::GPB);
+    __bf16* z_lo = reinterpret_cast<__bf16*>(smem_raw + 2 * G::GPB + G::ZPB);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int it0 = (w / 4) * G::ITW, jt0 = (w % 4) * G::JTW;
+    f32x4 acc[G::ITW][G::JTW];
+#pragma unroll
+    for (int i = 0; i < G::ITW; ++i)
+#pragma unroll
+        for (int j = 0; j < G::JTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 pf[G::PF];
+    auto prefetch = [&](int k) {
+        const int t = tile_list[k];
+        const int64_t start = tile_start[t];
+        const int cnt = tile_count[t];
+#pragma unroll
+        for (int u = 0; u < G::PF; ++u) {
+            const int f = tid + u * G::NT;
+            const bool isg = f < G::F4G;
+            const int fz = f - G::F4G;
+            const int row = isg ? f / (3 * H / 4) : fz / (2 * H / 4);
+            const float* src = isg ? dgrows + start * 3 * H + (int64_t)f * 4 : zrows + start * 2 * H + (int64_t)fz * 4;
+            if (row < cnt) pf[u] = *reinterpret_cast<const f32x4*>(src);
+            else pf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    int k = blockIdx.x;
+    if (k < ntiles) prefetch(k);
+    for (; k < ntiles; k += gridDim.x) {
+#pragma unroll
+        for (int u = 0; u < G::PF; ++u) {
+            const int f = tid + u * G::NT;
+            const bool isg = f < G::F4G;
+            const int fz = f - G::F4G;
+            const int row = isg ? f / (3 * H / 4) : fz / (2 * H / 4);
+            const int c4 = isg ? f % (3 * H / 4) : fz % (2 * H / 4);
+            bf16x4 hi, lo;
+            split4(f4(pf[u]), hi, lo);
+            if (isg) { st_bf4(g_hi + row * G::LDG + 4 * c4, hi); st_bf4(g_lo + row * G::LDG + 4 * c4, lo); }
+            else { st_bf4(z_hi + row * G::LDZ + 4 * c4, hi); st_bf4(z_lo + row * G::LDZ + 4 * c4, lo); }
+        }
+        lds_barrier();
+        if (k + (int)gridDim.x < ntiles) prefetch(k + gridDim.x);
+#pragma unroll
+        for (int ks = 0; ks < kTileRows / 32; ++ks) {
+            bf16x8 bh[G::JTW], bl[G::JTW];
+#pragma unroll
+            for (int j = 0; j < G::JTW; ++j) {
+                bh[j] = ldfrag_tr(z_hi, G::LDZ, 32 * ks, (jt0 + j) * 16);
+                bl[j] = ldfrag_tr(z_lo, G::LDZ, 32 * ks, (jt0 + j) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < G::ITW; ++i) {
+                const bf16x8 ah = ldfrag_tr(g_hi, G::LDG, 32 * ks, (it0 + i) * 16), al = ldfrag_tr(g_lo, G::LDG, 32 * ks, (it0 + i) * 16);
+#pragma unroll
+                for (int j = 0; j < G::JTW; ++j) mma_x3(acc[i][j], ah, al, bh[j], bl[j]);
+            }
+        }
+        lds_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < G::ITW; ++i)
+#pragma unroll
+        for (int j = 0; j < G::JTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                atomicAdd(dW + (int64_t)((it0 + i) * 16 + q * 4 + e) * 2 * H + (jt0 + j) * 16 + r, acc[i][j][e]);
+}
+
+// d_attn_u, dbvc, dbih, dbhh += sums of the per-workgroup slabs; grid (T, 16): 16 adders per address
+template <int H>
+__global__ __launch_bounds__(256) void k_level_small_reduce(const float* wslab, int nslab, int T, float* d_attn_u, float* dbvc,
+                                                           float* dbih, float* dbhh) {
+    const int g = blockIdx.x;
+    for (int i = threadIdx.x; i < 11 * H; i += 256) {
+        float acc = 0.f;
+        for (int b = blockIdx.y; b < nslab; b += gridDim.y) acc += wslab[((int64_t)b * T + g) * (11 * H) + i];
+        float* dst = i < 2 * H ? d_attn_u + (int64_t)g * 2 * H + i
+                   : i < 5 * H ? dbvc + (int64_t)g * 3 * H + (i - 2 * H)
+                   : i < 8 * H ? dbih + (int64_t)g * 3 * H + (i - 5 * H) : dbhh + (int64_t)g * 3 * H + (i - 8 * H);
+        atomicAdd(dst, acc);
     }
 }
 
@@ -413,32 +765,51 @@ int launch_level_x3(bool bwd, const LevelX3Args& a, int ntiles, hipStream_t st) 
     if (bwd) {
         static bool set_b = false;
         if (!set_b) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_bwd_x3<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_b = true; }
-        hipLaunchKernelGGL(k_level_bwd_x3<H>, dim3(ntiles), dim3(kThreads), M::bwd_bytes, st, a);
+        hipLaunchKernelGGL(k_level_bwd_x3<H>, dim3(ntiles), dim3(kLT), M::bwd_bytes, st, a);
     } else {
         static bool set_f = false;
         if (!set_f) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_fwd_x3<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_f = true; }
-        hipLaunchKernelGGL(k_level_fwd_x3<H>, dim3(ntiles), dim3(kThreads), M::fwd_bytes, st, a);
+        hipLaunchKernelGGL(k_level_fwd_x3<H>, dim3(ntiles), dim3(kLT), M::fwd_bytes, st, a);
     }
+    MGV_LAUNCH_RET();
+}
+
+template <int H>
+int launch_sweep_wgrad(const LevelX3Args& a, const int32_t* tile_list, int ntiles, float* dW, hipStream_t st) {
+    using G = WgradGeom<H>;
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_wgrad_x3<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    hipLaunchKernelGGL(k_sweep_wgrad_x3<H>, dim3(std::min(ntiles, 256)), dim3(G::NT), G::smem_bytes, st, a.dgrows, a.zrows, tile_list, ntiles,
+                       a.tile_start, a.tile_count, dW);
     MGV_LAUNCH_RET();
 }
 
 }  // namespace mgv
 
+#ifdef MGV_STAMPS
+static unsigned long long* g_lvl_stamps = nullptr;
+extern "C" int mgv_diag_set_level_stamps(void* p) { g_lvl_stamps = static_cast<unsigned long long*>(p); return 0; }
+#define MGV_SET_LVL_STAMPS(a) (a).stamps = g_lvl_stamps
+#else
+#define MGV_SET_LVL_STAMPS(a)
+#endif
+
 extern "C" int mgv_func_sweep_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                                     const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
-                                     const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src, const float* hs,
-                                     float* hf, const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
-                                     const float* bhh, void* stream) {
-    MGV_CHECK_ARG(N >= 0 && T >= 1 && num_levels >= 0 && level_tile_ptr_host && hs && hf && attn_u && wpack_bf16 && bvc && bih && bhh && in_ptr);
+                                     const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
+                                     const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
+                                     const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
+                                     const void* wpack_bf16, const float* bvc, const float* bih, const float* bhh, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && T >= 1 && T <= mgv::kMaxSlots && num_levels >= 0 && level_tile_ptr_host && hs && hf && attn_u && wpack_bf16 && bvc && bih && bhh && in_ptr);
     mgv::LevelX3Args a{};
-    a.N = N; a.T = T; a.order = order; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot;
+    MGV_SET_LVL_STAMPS(a);
+    a.N = N; a.T = T; a.order = order; a.order_span = order_span; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot;
     a.in_ptr = in_ptr; a.in_src = in_src; a.hs = hs; a.hf = hf; a.attn_u = attn_u; a.wpack = static_cast<const __bf16*>(wpack_bf16);
     a.bvc = bvc; a.bih = bih; a.bhh = bhh;
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (int lv = 1; lv < num_levels; ++lv) {
         const int t0 = level_tile_ptr_host[lv], t1 = level_tile_ptr_host[lv + 1];
         if (t1 <= t0) continue;
-        MGV_CHECK_ARG(order && tile_start && tile_count && tile_slot && in_src);
+        MGV_CHECK_ARG(order && order_span && tile_start && tile_count && tile_slot && in_src);
         a.tile_begin = t0;
         int rc;
         switch (H) {
@@ -452,28 +823,41 @@ extern "C" int mgv_func_sweep_fwd_x3(int H, int64_t N, int T, int num_levels, co
 }
 
 extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                                     const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
-                                     const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src,
-                                     const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_slot,
-                                     const uint8_t* gslot, const float* hs, const float* hf, const float* attn_u,
-                                     const void* wpack_bf16, const float* bvc, const float* bih, const float* bhh,
-                                     const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc, float* d_attn_u,
-                                     float* dWvc, float* dbvc, float* dbih, float* dbhh, void* stream) {
-    MGV_CHECK_ARG(N >= 0 && T >= 1 && num_levels >= 0 && level_tile_ptr_host && hs && hf && attn_u && wpack_bf16 && bvc && bih && bhh);
+                                     const int32_t* order, const int32_t* order_span, int64_t n_active,
+                                     const int32_t* tile_start, const int32_t* tile_count, const int32_t* tile_slot,
+                                     const int32_t* slot_tiles, const int32_t* slot_tile_ptr_host, const int32_t* in_ptr,
+                                     const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                     const int32_t* out_slot, const uint8_t* gslot, const float* hs, const float* hf,
+                                     const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
+                                     const float* bhh, const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc,
+                                     float* d_attn_u, float* dWvc, float* dbvc, float* dbih, float* dbhh, float* scratch,
+                                     int64_t scratch_elems, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && T >= 1 && T <= mgv::kMaxSlots && num_levels >= 0 && n_active >= 0 && level_tile_ptr_host && hs && hf &&
+                  attn_u && wpack_bf16 && bvc && bih && bhh);
     MGV_CHECK_ARG(in_ptr && out_ptr && gslot && ghf && ghs && dzb && d_attn_u && dWvc && dbvc && dbih && dbhh);
     if (N == 0) return MGV_OK;
     mgv::LevelX3Args a{};
-    a.N = N; a.T = T; a.order = order; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot;
+    MGV_SET_LVL_STAMPS(a);
+    a.N = N; a.T = T; a.order = order; a.order_span = order_span; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot;
     a.in_ptr = in_ptr; a.in_src = in_src; a.hs = hs; a.hf = const_cast<float*>(hf); a.attn_u = attn_u;
     a.wpack = static_cast<const __bf16*>(wpack_bf16); a.bvc = bvc; a.bih = bih; a.bhh = bhh;
     a.out_ptr = out_ptr; a.out_dst = out_dst; a.out_slot = out_slot; a.gslot = gslot;
     a.ghf = ghf; a.ghs = ghs; a.dzb = dzb; a.alpha = alpha; a.dsc = dsc; a.d_attn_u = d_attn_u; a.dWvc = dWvc; a.dbvc = dbvc;
     a.dbih = dbih; a.dbhh = dbhh;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    int nslab = 0;
+    for (int lv = 1; lv < num_levels; ++lv) nslab = std::max(nslab, level_tile_ptr_host[lv + 1] - level_tile_ptr_host[lv]);
+    const int64_t slab_elems = (int64_t)nslab * T * 11 * H;
+    if (nslab > 0) {
+        MGV_CHECK_ARG(scratch && scratch_elems >= n_active * 5 * H + slab_elems && slot_tiles && slot_tile_ptr_host);
+        a.dgrows = scratch; a.zrows = scratch + n_active * 3 * H; a.wslab = a.zrows + n_active * 2 * H;
+        const hipError_t e = hipMemsetAsync(a.wslab, 0, slab_elems * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
     for (int lv = num_levels - 1; lv >= 1; --lv) {
         const int t0 = level_tile_ptr_host[lv], t1 = level_tile_ptr_host[lv + 1];
         if (t1 <= t0) continue;
-        MGV_CHECK_ARG(order && tile_start && tile_count && tile_slot && in_src && out_dst && out_slot && alpha && dsc);
+        MGV_CHECK_ARG(order && order_span && tile_start && tile_count && tile_slot && in_src && out_dst && out_slot && alpha && dsc);
         a.tile_begin = t0;
         int rc;
         switch (H) {
@@ -482,6 +866,20 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
             default: return MGV_EUNSUPPORTED;
         }
         if (rc != MGV_OK) return rc;
+    }
+    if (nslab > 0) {
+        switch (H) {
+            case 32: hipLaunchKernelGGL(mgv::k_level_small_reduce<32>, dim3(T, 16), dim3(256), 0, st, a.wslab, nslab, T, d_attn_u, dbvc, dbih, dbhh); break;
+            case 64: hipLaunchKernelGGL(mgv::k_level_small_reduce<64>, dim3(T, 16), dim3(256), 0, st, a.wslab, nslab, T, d_attn_u, dbvc, dbih, dbhh); break;
+            default: return MGV_EUNSUPPORTED;
+        }
+        for (int g = 0; g < T; ++g) {
+            const int nt = slot_tile_ptr_host[g + 1] - slot_tile_ptr_host[g];
+            if (nt <= 0) continue;
+            const int rc = H == 32 ? mgv::launch_sweep_wgrad<32>(a, slot_tiles + slot_tile_ptr_host[g], nt, dWvc + (int64_t)g * 3 * H * 2 * H, st)
+                                   : mgv::launch_sweep_wgrad<64>(a, slot_tiles + slot_tile_ptr_host[g], nt, dWvc + (int64_t)g * 3 * H * 2 * H, st);
+            if (rc != MGV_OK) return rc;
+        }
     }
     const int rows_per_block = mgv::kThreads / (H / 4);
     const int grid = mgv::grid_for((N + rows_per_block - 1) / rows_per_block, 8);

@@ -34,18 +34,7 @@ struct StageX3Args {
     float* dWc; float* dbc; float* dWhh; float* dbhh; float* dxtab; float* dlnw; float* dlnb;
 };
 
-#ifdef MGV_STAMPS
-// in-kernel phase stamps (diagnostic build only; never quote its run time, read the SHARES)
-#define STAMP_DECL unsigned long long st_t0_ = 0, st_acc_[16] = {0}; int st_k_ = 0;
-#define STAMP_BEGIN do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st_k_ = 0; } while (0)
-#define STAMP(k) do { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); st_acc_[k] += t_ - st_t0_; st_t0_ = t_; } while (0)
-#define STAMP_FLUSH(a) do { if ((threadIdx.x & 63) == 0 && (a).stamps) for (int k_ = 0; k_ < 16; ++k_) atomicAdd((a).stamps + (threadIdx.x >> 6) * 16 + k_, st_acc_[k_]); } while (0)
-#else
-#define STAMP_DECL
-#define STAMP_BEGIN
-#define STAMP(k)
-#define STAMP_FLUSH(a)
-#endif
+#include "mgv_stamps.h"
 
 constexpr int kMaxClsX3 = 8;
 constexpr int kTPR = 2;                 // gate-gradient tiles staged in LDS per round of the backward phase E (4 spills registers: 7.4 vs 4.6 ms)

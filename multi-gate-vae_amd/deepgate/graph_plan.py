@@ -87,6 +87,10 @@ class GraphPlan:
         key = lv[nodes] * T + gslot[nodes]
         o = torch.sort(key, stable=True)
         self.order = nodes[o.indices].to(torch.int32).contiguous()
+        # CSR spans in sweep order {in0, in1, out0, out1}: a tile reaches its edge lists with one load per row
+        on = nodes[o.indices]
+        self.order_span = torch.stack([self.in_ptr[on], self.in_ptr[on + 1], self.out_ptr[on], self.out_ptr[on + 1]],
+                                      1).to(torch.int32).contiguous()
         keys, counts = torch.unique_consecutive(o.values, return_counts=True)
         starts = torch.cumsum(counts, 0) - counts
         ntile = (counts + TILE - 1) // TILE
@@ -100,6 +104,11 @@ class GraphPlan:
         self.tile_start = t_start.to(torch.int32).contiguous()
         self.tile_count = t_count.to(torch.int32).contiguous()
         self.tile_slot = t_slot.to(torch.int32).contiguous()
+        # tiles grouped by slot, for the per-slot weight-gradient pass of the backward sweep
+        self.slot_tiles = torch.sort(t_slot, stable=True).indices.to(torch.int32).contiguous()
+        stp = torch.zeros(T + 1, dtype=torch.int64, device=dev)
+        stp[1:] = torch.cumsum(torch.bincount(t_slot, minlength=T), 0)
+        self.slot_tile_ptr = [int(v) for v in stp.tolist()]        # host copy
         per_level = torch.bincount(t_level, minlength=max(self.num_levels, 1))
         ltp = torch.zeros(max(self.num_levels, 1) + 1, dtype=torch.int64, device=dev)
         ltp[1:] = torch.cumsum(per_level, 0)

@@ -279,8 +279,8 @@ class FuncSweepFn(torch.autograd.Function):
         ltp = (_hip.ctypes.c_int32 * len(plan.level_tile_ptr))(*plan.level_tile_ptr)
         wpack = sweep_wpack(par[1]) if use_x3(H) else None
         if wpack is not None:
-            _hip.call('mgv_func_sweep_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.tile_start),
-                      ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
+            _hip.call('mgv_func_sweep_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.order_span),
+                      ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
                       ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]))
         else:
             _hip.call('mgv_func_sweep_fwd', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.tile_start),
@@ -298,17 +298,22 @@ class FuncSweepFn(torch.autograd.Function):
         T = par[0].shape[0]
         dev = hs.device
         ghf = check(ghf.contiguous(), F32, 'ghf')
-        ghs = torch.zeros(N, H, dtype=F32, device=dev)
+        ghs = (torch.empty if ctx.wpack is not None else torch.zeros)(N, H, dtype=F32, device=dev)
         dzb = torch.empty(N, 2 * H, dtype=F32, device=dev)
         alpha = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
         dsc = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
         grads = [torch.zeros_like(t) for t in par]
         if ctx.wpack is not None:
-            _hip.call('mgv_func_sweep_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.tile_start),
-                      ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr),
-                      ptr(plan.out_dst), ptr(plan.out_slot), ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]),
-                      ptr(ctx.wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]), ptr(ghf), ptr(ghs), ptr(dzb), ptr(alpha),
-                      ptr(dsc), *[ptr(g) for g in grads])
+            ltp = plan.level_tile_ptr
+            widest = max([ltp[i + 1] - ltp[i] for i in range(1, len(ltp) - 1)] + [1])
+            scratch = torch.empty(plan.n_active * 5 * H + widest * T * 11 * H, dtype=F32, device=dev)
+            stp = (_hip.ctypes.c_int32 * len(plan.slot_tile_ptr))(*plan.slot_tile_ptr)
+            _hip.call('mgv_func_sweep_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.order_span),
+                      plan.n_active, ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.slot_tiles), stp,
+                      ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr), ptr(plan.out_dst), ptr(plan.out_slot),
+                      ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]), ptr(ctx.wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]),
+                      ptr(ghf), ptr(ghs), ptr(dzb), ptr(alpha), ptr(dsc), *[ptr(g) for g in grads], ptr(scratch),
+                      scratch.numel())
             return (None, ghs, *grads)
         WvcT = par[1].transpose(1, 2).contiguous()
         _hip.call('mgv_func_sweep_bwd', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.tile_start),
