@@ -116,7 +116,11 @@ __device__ __forceinline__ SmallVecs stage_small(const StageX3Args& a, float* ba
 // the CSR pointers and indices of tile t+1 are fetched while tile t is being computed and parked in LDS;
 // the row phase of a tile then consists of independent loads only (own rows + up to 4 neighbour rows
 // per lane group in flight at once).
-struct IdxLds { int* ptr; int* idx; __device__ int* dmax() const { return ptr + 72; } };   // one of two LDS buffers
+// one of two LDS buffers, addressed by arithmetic on the shared-memory base (a dynamically indexed array of pointer
+// structs would hide the address space from the compiler and turn every index read into a flat_load)
+constexpr int kIdxStride = kPtrPad + kIdxCap + 8;
+struct IdxLds { int* ptr; int* idx; __device__ int* dmax() const { return ptr + 72; } };
+__device__ __forceinline__ IdxLds idx_lds(int* idx_base, int b) { return IdxLds{idx_base + b * kIdxStride, idx_base + b * kIdxStride + kPtrPad}; }
 
 __device__ __forceinline__ int ptr_prefetch(const StageX3Args& a, int64_t tile, int64_t ntiles) {
     if (tile >= ntiles || threadIdx.x > kTileRows) return 0;
@@ -351,14 +355,13 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
         }
 
     int* idx_base = reinterpret_cast<int*>(smem_raw + M::f_idx);
-    IdxLds ib[2] = {{idx_base, idx_base + kPtrPad}, {idx_base + kPtrPad + kIdxCap + 8, idx_base + 2 * kPtrPad + kIdxCap + 8}};
     int rp = ptr_prefetch(a, blockIdx.x, ntiles);
-    if (tid <= kTileRows) ib[0].ptr[tid] = rp;
+    if (tid <= kTileRows) idx_lds(idx_base, 0).ptr[tid] = rp;
     __syncthreads();
     int ri[kIdxCap / kThreadsF];
-    idx_prefetch<kThreadsF>(a, ib[0].ptr, ri);
-    idx_commit<kThreadsF>(ib[0].idx, ri);
-    tile_dmax(ib[0].ptr, ib[0].dmax());
+    idx_prefetch<kThreadsF>(a, idx_lds(idx_base, 0).ptr, ri);
+    idx_commit<kThreadsF>(idx_lds(idx_base, 0).idx, ri);
+    tile_dmax(idx_lds(idx_base, 0).ptr, idx_lds(idx_base, 0).dmax());
     rp = ptr_prefetch(a, (int64_t)blockIdx.x + gridDim.x, ntiles);
     __syncthreads();
     int b = 0;
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
             float4 acc[RPG], own[RPG], dy[RPG];
             float deg[RPG];
             int cls[RPG];
-            tile_rows<H, RPG, false>(a, base, grp, S::GROUPS, lr, ib[b].ptr, ib[b].idx, *ib[b].dmax(), acc, own, dy, deg, cls);
+            tile_rows<H, RPG, false>(a, base, grp, S::GROUPS, lr, idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).idx, *idx_lds(idx_base, b).dmax(), acc, own, dy, deg, cls);
 #pragma unroll
             for (int rr = 0; rr < RPG; ++rr) {
                 const int row = grp + rr * S::GROUPS;
@@ -384,14 +387,14 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
                 if (lr == 0) { sv.deg[row] = deg[rr]; sv.cls[row] = cls[rr]; }
             }
         }
-        if (tid <= kTileRows) ib[b ^ 1].ptr[tid] = rp;       // pointers of the next tile (requested one tile ago)
+        if (tid <= kTileRows) idx_lds(idx_base, b ^ 1).ptr[tid] = rp;       // pointers of the next tile (requested one tile ago)
         STAMP(0);
         __syncthreads();
         STAMP(1);
         // next tile's indices and the tile after's pointers fly during the dense part + epilogue
-        idx_prefetch<kThreadsF>(a, ib[b ^ 1].ptr, ri);
+        idx_prefetch<kThreadsF>(a, idx_lds(idx_base, b ^ 1).ptr, ri);
         rp = ptr_prefetch(a, tile + 2 * (int64_t)gridDim.x, ntiles);
-        tile_dmax(ib[b ^ 1].ptr, ib[b ^ 1].dmax());
+        tile_dmax(idx_lds(idx_base, b ^ 1).ptr, idx_lds(idx_base, b ^ 1).dmax());
         // ---- dense part: LDS fragments x register-resident weights
         f32x4 ar[S::RTW], az[S::RTW], ani[S::RTW], anh[S::RTW];
 #pragma unroll
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
             }
             if (node < a.N) st4(a.h_out + node * H + 4 * lr, v);
         }
-        idx_commit<kThreadsF>(ib[b ^ 1].idx, ri);
+        idx_commit<kThreadsF>(idx_lds(idx_base, b ^ 1).idx, ri);
         STAMP(7);
         __syncthreads();
     }
@@ -550,14 +553,13 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
     __syncthreads();
 
     int* idx_base = reinterpret_cast<int*>(smem_raw + M::b_idx);
-    IdxLds ib[2] = {{idx_base, idx_base + kPtrPad}, {idx_base + kPtrPad + kIdxCap + 8, idx_base + 2 * kPtrPad + kIdxCap + 8}};
     int rp = ptr_prefetch(a, blockIdx.x, ntiles);
-    if (tid <= kTileRows) ib[0].ptr[tid] = rp;
+    if (tid <= kTileRows) idx_lds(idx_base, 0).ptr[tid] = rp;
     __syncthreads();
     int ri[kIdxCap / kThreadsX3];
-    idx_prefetch<kThreadsX3>(a, ib[0].ptr, ri);
-    idx_commit<kThreadsX3>(ib[0].idx, ri);
-    tile_dmax(ib[0].ptr, ib[0].dmax());
+    idx_prefetch<kThreadsX3>(a, idx_lds(idx_base, 0).ptr, ri);
+    idx_commit<kThreadsX3>(idx_lds(idx_base, 0).idx, ri);
+    tile_dmax(idx_lds(idx_base, 0).ptr, idx_lds(idx_base, 0).dmax());
     rp = ptr_prefetch(a, (int64_t)blockIdx.x + gridDim.x, ntiles);
     __syncthreads();
     int b = 0;
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
             float4 acc[RPG], own[RPG], dy[RPG];
             float deg[RPG];
             int cls[RPG];
-            tile_rows<H, RPG, true>(a, base, grp, S::GROUPS, lr, ib[b].ptr, ib[b].idx, *ib[b].dmax(), acc, own, dy, deg, cls);
+            tile_rows<H, RPG, true>(a, base, grp, S::GROUPS, lr, idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).idx, *idx_lds(idx_base, b).dmax(), acc, own, dy, deg, cls);
 #pragma unroll
             for (int rr = 0; rr < RPG; ++rr) {
                 const int row = grp + rr * S::GROUPS;
@@ -591,16 +593,16 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                 }
             }
         }
-        if (tid <= kTileRows) ib[b ^ 1].ptr[tid] = rp;
+        if (tid <= kTileRows) idx_lds(idx_base, b ^ 1).ptr[tid] = rp;
         STAMP(0);
         __syncthreads();
         STAMP(1);
         // ---- B. recompute gates; keep the own-row values (hi+lo) for the GRU backward
         f32x4 ar[S::RTW][S::HCW], az[S::RTW][S::HCW], ani[S::RTW][S::HCW], anh[S::RTW][S::HCW];
         stage_gemm_x3<H>(a.wpack, agg_hi, agg_lo, hin_hi, hin_lo, ar, az, ani, anh);
-        idx_prefetch<kThreadsX3>(a, ib[b ^ 1].ptr, ri);          // after the weight fragments (vmcnt is in order); committed at the tile's end
+        idx_prefetch<kThreadsX3>(a, idx_lds(idx_base, b ^ 1).ptr, ri);          // after the weight fragments (vmcnt is in order); committed at the tile's end
         rp = ptr_prefetch(a, tile + 2 * (int64_t)gridDim.x, ntiles);
-        tile_dmax(ib[b ^ 1].ptr, ib[b ^ 1].dmax());
+        tile_dmax(idx_lds(idx_base, b ^ 1).ptr, idx_lds(idx_base, b ^ 1).dmax());
         STAMP(2);
 #pragma unroll
         for (int i = 0; i < S::RTW; ++i)
@@ -791,7 +793,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                 }
             }
         }
-        idx_commit<kThreadsX3>(ib[b ^ 1].idx, ri);
+        idx_commit<kThreadsX3>(idx_lds(idx_base, b ^ 1).idx, ri);
         __syncthreads();
         STAMP(9);
     }
