@@ -83,6 +83,14 @@ int mgv_linear_wgrad(int64_t N, const float* X1, int K1, int ld1, const float* X
 int mgv_gather_sum(int H, int64_t N, const float* h, const int32_t* nbr_ptr, const int32_t* nbr_idx,
                    float* agg, float* deg, void* stream);
 
+/* First half round of an encoder (digae_layer.py:260 starts every node from ones): an output row depends only on
+ * the node's (degree, feature class) pair, class_id[N] numbers the pairs 0..C-1.
+ * expand: out[i] = table[class_id[i]]; pull_sum: out[c] += sum over nodes of class c of
+ * (gy_direct[i] + sum_{j in nbr(i)} gy_agg[j]) (gy_agg may be NULL); C * H * 4 <= 64 KiB. */
+int mgv_class_expand(int H, int64_t N, const float* table, const int32_t* class_id, float* out, void* stream);
+int mgv_class_pull_sum(int H, int64_t N, const float* gy_direct, const float* gy_agg, const int32_t* nbr_ptr,
+                       const int32_t* nbr_idx, const int32_t* class_id, int C, float* out, void* stream);
+
 /* ---- levelised functional sweep (dg_ae_model_aig.py:70-97 and mig/xag/xmg siblings; arch/tfmlp.py:38-46;
  * utils/dag_utils.py:91-105 is replaced by the tile tables).  T gate types ("slots"), per slot:
  *   attn_u[T][2H] = Wk^T w_attn[H:],  Wvc[T][3H][2H] = W_ih Wv,  bvc[T][3H] = W_ih bv,  bih/bhh[T][3H].

@@ -155,6 +155,85 @@ __global__ __launch_bounds__(kThreads) void k_gather_sum(int64_t N, const float*
     }
 }
 
+// First half round of an encoder: every node starts from the same state (ones), so a node's output row depends
+// only on its (degree, feature class) pair.  Forward = the stage kernel on one representative row per pair + this
+// expansion; backward = per-pair sums of the incoming gradient (with the neighbour pull fused) + the stage backward
+// on the representative rows (parameter gradients are linear in the incoming gradient).
+template <int H>
+__global__ __launch_bounds__(kThreads) void k_class_expand(int64_t N, const float* table, const int32_t* class_id, float* out) {
+    constexpr int LPR = H / 4;
+    const int64_t stride = (int64_t)gridDim.x * kThreads / LPR;
+    const int lr = threadIdx.x % LPR;
+    for (int64_t node = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LPR; node < N; node += stride)
+        st4(out + node * H + 4 * lr, ld4(table + (int64_t)class_id[node] * H + 4 * lr));
+}
+
+// CREG > 0: at most CREG classes, every lane keeps one partial sum per class in registers (the LDS atomic unit
+// would otherwise serialise: most rows of a wave share a class) and adds them to LDS once at the end
+template <int H, int CREG>
+__global__ __launch_bounds__(kThreads) void k_class_pull_sum(int64_t N, const float* gy_direct, const float* gy_agg, const int32_t* ptr,
+                                                            const int32_t* idx, const int32_t* class_id, int C, float* out) {
+    constexpr int LPR = H / 4;
+    extern __shared__ __attribute__((aligned(16))) float s_acc[];        // [C][H]
+    float4 racc[CREG > 0 ? CREG : 1];
+#pragma unroll
+    for (int c = 0; c < (CREG > 0 ? CREG : 1); ++c) racc[c] = zero4();
+    for (int i = threadIdx.x; i < C * H; i += kThreads) s_acc[i] = 0.f;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * kThreads / LPR;
+    const int lr = threadIdx.x % LPR;
+    constexpr int U = 4, D = 2;          // rows per lane group in flight, neighbours per row gathered together
+    for (int64_t node0 = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / LPR; node0 < N; node0 += U * stride) {
+        int e0[U], e1[U], cls[U];
+        f32x4 own[U], nb[U][D];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t node = node0 + u * stride;
+            e0[u] = e1[u] = 0; cls[u] = 0;
+            if (node < N) {
+                own[u] = *reinterpret_cast<const f32x4*>(gy_direct + node * H + 4 * lr);
+                cls[u] = class_id[node];
+                if (gy_agg) { e0[u] = ptr[node]; e1[u] = ptr[node + 1]; }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if (e0[u] + k < e1[u]) nb[u][k] = *reinterpret_cast<const f32x4*>(gy_agg + (int64_t)idx[e0[u] + k] * H + 4 * lr);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t node = node0 + u * stride;
+            if (node >= N) continue;
+            float4 acc = make_float4(own[u][0], own[u][1], own[u][2], own[u][3]);
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+                if (e0[u] + k < e1[u]) acc = add4(acc, make_float4(nb[u][k][0], nb[u][k][1], nb[u][k][2], nb[u][k][3]));
+            for (int e = e0[u] + D; e < e1[u]; ++e) acc = add4(acc, ld4(gy_agg + (int64_t)idx[e] * H + 4 * lr));
+            if (CREG > 0) {
+#pragma unroll
+                for (int c = 0; c < CREG; ++c) {
+                    const float m = cls[u] == c ? 1.0f : 0.0f;
+                    racc[c] = fma4(m, acc, racc[c]);
+                }
+            } else {
+                float* d = s_acc + cls[u] * H + 4 * lr;
+                atomicAdd(d + 0, acc.x); atomicAdd(d + 1, acc.y); atomicAdd(d + 2, acc.z); atomicAdd(d + 3, acc.w);
+            }
+        }
+    }
+    if (CREG > 0) {
+#pragma unroll
+        for (int c = 0; c < CREG; ++c)
+            if (c < C) {
+                float* d = s_acc + c * H + 4 * lr;
+                atomicAdd(d + 0, racc[c].x); atomicAdd(d + 1, racc[c].y); atomicAdd(d + 2, racc[c].z); atomicAdd(d + 3, racc[c].w);
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * H; i += kThreads) atomicAdd(out + i, s_acc[i]);
+}
+
 template <int M>
 int launch_linear_fwd(const LinArgs& a, hipStream_t st) {
     const int K = a.K1 + a.K2;
@@ -225,6 +304,48 @@ extern "C" int mgv_gather_sum(int H, int64_t N, const float* h, const int32_t* n
         case 32: hipLaunchKernelGGL(mgv::k_gather_sum<32>, dim3(grid), dim3(mgv::kThreads), 0, st, N, h, nbr_ptr, nbr_idx, agg, deg); break;
         case 64: hipLaunchKernelGGL(mgv::k_gather_sum<64>, dim3(grid), dim3(mgv::kThreads), 0, st, N, h, nbr_ptr, nbr_idx, agg, deg); break;
         case 128: hipLaunchKernelGGL(mgv::k_gather_sum<128>, dim3(grid), dim3(mgv::kThreads), 0, st, N, h, nbr_ptr, nbr_idx, agg, deg); break;
+        default: return MGV_EUNSUPPORTED;
+    }
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_class_expand(int H, int64_t N, const float* table, const int32_t* class_id, float* out, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && table && class_id && out);
+    if (N == 0) return MGV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows_per_block = mgv::kThreads / (H / 4);
+    const int grid = mgv::grid_for((N + rows_per_block - 1) / rows_per_block, 16);
+    switch (H) {
+        case 16: hipLaunchKernelGGL(mgv::k_class_expand<16>, dim3(grid), dim3(mgv::kThreads), 0, st, N, table, class_id, out); break;
+        case 32: hipLaunchKernelGGL(mgv::k_class_expand<32>, dim3(grid), dim3(mgv::kThreads), 0, st, N, table, class_id, out); break;
+        case 64: hipLaunchKernelGGL(mgv::k_class_expand<64>, dim3(grid), dim3(mgv::kThreads), 0, st, N, table, class_id, out); break;
+        case 128: hipLaunchKernelGGL(mgv::k_class_expand<128>, dim3(grid), dim3(mgv::kThreads), 0, st, N, table, class_id, out); break;
+        default: return MGV_EUNSUPPORTED;
+    }
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_class_pull_sum(int H, int64_t N, const float* gy_direct, const float* gy_agg, const int32_t* nbr_ptr,
+                                  const int32_t* nbr_idx, const int32_t* class_id, int C, float* out, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && gy_direct && class_id && out && C >= 1 && (int64_t)C * H * 4 <= 64 * 1024 && (!gy_agg || (nbr_ptr && nbr_idx)));
+    if (N == 0) return MGV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows_per_block = mgv::kThreads / (H / 4);
+    const int grid = mgv::grid_for((N + rows_per_block - 1) / rows_per_block, 8);
+    const size_t shm = (size_t)C * H * sizeof(float);
+    switch (H) {
+        case 16: if (C <= 8) hipLaunchKernelGGL((mgv::k_class_pull_sum<16, 8>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
+                 else hipLaunchKernelGGL((mgv::k_class_pull_sum<16, 0>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
+                 break;
+        case 32: if (C <= 8) hipLaunchKernelGGL((mgv::k_class_pull_sum<32, 8>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
+                 else hipLaunchKernelGGL((mgv::k_class_pull_sum<32, 0>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
+                 break;
+        case 64: if (C <= 8) hipLaunchKernelGGL((mgv::k_class_pull_sum<64, 8>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
+                 else hipLaunchKernelGGL((mgv::k_class_pull_sum<64, 0>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
+                 break;
+        case 128: if (C <= 8) hipLaunchKernelGGL((mgv::k_class_pull_sum<128, 8>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
+                 else hipLaunchKernelGGL((mgv::k_class_pull_sum<128, 0>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
+                 break;
         default: return MGV_EUNSUPPORTED;
     }
     MGV_LAUNCH_RET();

@@ -164,10 +164,6 @@ __device__ __forceinline__ void stage_out_edges(const LevelX3Args& a, const LvlI
     }
 }
 
-// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain every outstanding global
-// load, store and atomic (vmcnt(0)), and these kernels exchange nothing through global memory inside a tile.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 __device__ __forceinline__ float4 f4(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
 
 // source rows of a node's first kInRegs in-edges, loaded together into registers the untaken path never writes

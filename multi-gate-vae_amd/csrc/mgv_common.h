@@ -105,6 +105,11 @@ struct WaveSplit {
     static constexpr int GROUPS = kThreads / LPR;      // rows processed concurrently by the block
 };
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup release/acquire fence: with
+// LDS-DMA loads in flight (the L2 prefetches) the compiler drains vmcnt(0) in front of it, which would expose the
+// very latency the prefetch is there to hide; no kernel here exchanges data through global memory inside a tile.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 inline int grid_for(int64_t tiles, int per_cu) {
     int64_t cap = 256LL * per_cu;
     return (int)(tiles < cap ? (tiles < 1 ? 1 : tiles) : cap);

@@ -56,6 +56,31 @@ class GraphPlan:
         edges are flipped (`r_edge_index`, digae_layer.py:264)."""
         return (self.out_ptr, self.out_dst) if reverse else (self.in_ptr, self.in_src)
 
+    def first_stage_classes(self, xcls, max_classes=256):
+        """(degree, feature class) pairs of the forward CSR: every node enters the first half round of an encoder with
+        the same state (ones, digae_layer.py:260), so its output row there depends on that pair alone.  Returns
+        (class_id[N] int32, C, ptr[C+1], idx[sum deg], xcls[C]) — one representative row per pair whose `deg`
+        neighbours all point at row 0 (any row: the representatives' inputs are all ones) — or None when there are
+        more than `max_classes` pairs.  Cached per xcls tensor."""
+        key = (xcls.data_ptr(), int(xcls.numel()))
+        hit = getattr(self, '_stage1', None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        deg = (self.in_ptr[1:] - self.in_ptr[:-1]).long()
+        pair = deg * 256 + xcls.long()
+        uniq, inv = torch.unique(pair, return_inverse=True)
+        C = int(uniq.numel())
+        out = None
+        if 0 < C <= max_classes:
+            d = (uniq // 256)
+            ptr = torch.zeros(C + 1, dtype=torch.int64, device=self.device)
+            ptr[1:] = torch.cumsum(d, 0)
+            idx = torch.zeros(max(int(ptr[-1].item()), 1), dtype=torch.int32, device=self.device)
+            out = (inv.to(torch.int32).contiguous(), C, ptr.to(torch.int32).contiguous(), idx,
+                   (uniq % 256).to(torch.uint8).contiguous())
+        self._stage1 = (key, out)
+        return out
+
     def set_levels(self, gate, forward_level, gate_ids):
         """Bucket the nodes a Model updates: level >= 1 and gate id in `gate_ids` (list, position =
         aggregator slot).  Mirrors `layer_mask & <gate>_mask` of the reference level loop."""

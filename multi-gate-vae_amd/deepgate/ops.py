@@ -19,6 +19,8 @@ LN_EPS = 1e-5
 # products, fp32 accumulation; ~1e-5 relative per product, 3/16 of the fp32-MFMA cost), 'f32' = exact
 # fp32 MFMA.  Hidden widths the x3 kernels do not cover (H=16) always run in fp32.
 PRECISION = os.environ.get('MGV_PRECISION', 'x3')
+# first half round of an encoder from one kernel row per (degree, class) pair ('table') or over all nodes ('full')
+FIRST_STAGE_TABLE = os.environ.get('MGV_FIRST_STAGE', 'table') != 'full'
 
 
 def use_x3(H):
@@ -128,16 +130,26 @@ class StructEncoderFn(torch.autograd.Function):
         par = [t.detach().contiguous() for t in (xtab_f, Wc_f, bc_f, Whh_f, bhh_f, xtab_r, Wc_r, bc_r, Whh_r, bhh_r)]
         lw = ln_w.detach().contiguous() if ln_w is not None else None
         lb = ln_b.detach().contiguous() if ln_b is not None else None
-        h = torch.ones(N, H, dtype=F32, device=dev)          # node_state = ones (digae_layer.py:260)
         packs = (stage_wpack(par[1], par[3]), stage_wpack(par[6], par[8])) if use_x3(H) else (None, None)
+        # node_state = ones (digae_layer.py:260): the first half round sees identical rows, one kernel row per
+        # (degree, feature class) pair does for all nodes of the pair
+        first = plan.first_stage_classes(xcls) if (FIRST_STAGE_TABLE and rounds > 0 and N > 0) else None
+        h = None if first is not None else torch.ones(N, H, dtype=F32, device=dev)
         states = []
         for _ in range(rounds):
             for rev in (False, True):
                 p, i = plan.csr(rev)
                 w = par[5:] if rev else par[:5]
                 states.append(h)
-                h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)])
-        ctx.plan, ctx.xcls, ctx.rounds, ctx.packs = plan, xcls, rounds, packs
+                if h is None:
+                    cid, C, tp, ti, tx = first
+                    table = struct_stage_fwd(torch.ones(C, H, dtype=F32, device=dev), tp, ti, tx, w[0], w[1], w[2], w[3], w[4],
+                                             lw, lb, wpack=packs[0])
+                    h = torch.empty(N, H, dtype=F32, device=dev)
+                    _hip.call('mgv_class_expand', H, N, ptr(table), ptr(cid), ptr(h))
+                else:
+                    h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)])
+        ctx.plan, ctx.xcls, ctx.rounds, ctx.packs, ctx.first = plan, xcls, rounds, packs, first
         ctx.par, ctx.lw, ctx.lb, ctx.states = par, lw, lb, states
         return h
 
@@ -159,8 +171,18 @@ class StructEncoderFn(torch.autograd.Function):
                 w = par[5:] if rev else par[:5]
                 g = dict(acc['r' if rev else 'f'])
                 g['dln_w'], g['dln_b'] = dlw, dlb
-                g_direct, g_agg = struct_stage_bwd(ctx.states[k], p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb,
-                                                   g_direct, g_agg, g, need_input_grad=(k > 0), wpack=ctx.packs[int(rev)])
+                if k == 0 and ctx.first is not None:
+                    # parameter gradients are linear in the incoming gradient: sum it per (degree, class) pair,
+                    # then one backward row per pair
+                    cid, C, tp, ti, tx = ctx.first
+                    H = g_direct.shape[1]
+                    gsum = torch.zeros(C, H, dtype=F32, device=g_direct.device)
+                    _hip.call('mgv_class_pull_sum', H, plan.N, ptr(g_direct), ptr(g_agg), ptr(p), ptr(i), ptr(cid), C, ptr(gsum))
+                    struct_stage_bwd(torch.ones(C, H, dtype=F32, device=g_direct.device), tp, ti, tx, w[0], w[1], w[2], w[3], w[4],
+                                     lw, lb, gsum, None, g, need_input_grad=False, wpack=ctx.packs[0])
+                else:
+                    g_direct, g_agg = struct_stage_bwd(ctx.states[k], p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb,
+                                                       g_direct, g_agg, g, need_input_grad=(k > 0), wpack=ctx.packs[int(rev)])
                 k -= 1
         ctx.states = None
         f, r = acc['f'], acc['r']
