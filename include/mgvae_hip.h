@@ -78,6 +78,14 @@ int mgv_linear_fwd(int64_t N, const float* X1, int K1, int ld1, const float* X2,
 /* dW[M][K1+K2] += dY^T [X1|X2],  db[M] += column sums of dY (db may be NULL) */
 int mgv_linear_wgrad(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
                      const float* dY, int lddy, int M, float* dW, float* db, void* stream);
+/* the same layers on bf16x3 split-precision MFMA (see mgv_struct_stage_fwd_x3): HBM-bound instead of fp32-MFMA-bound.
+ * (M, K = K1 + K2) must be one of the shapes mgv_linear_x3_supported() accepts (the model's layer shapes at H=64/32);
+ * forward weights arrive as wpack_bf16[2][M*K] = {W_hi, W_lo} in MFMA fragment order (see mgv_func_sweep_fwd_x3). */
+int mgv_linear_x3_supported(int M, int K);
+int mgv_linear_fwd_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
+                      const void* wpack_bf16, const float* b, int M, float* Y, int ldy, void* stream);
+int mgv_linear_wgrad_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
+                        const float* dY, int lddy, int M, float* dW, float* db, void* stream);
 /* agg[i] = sum_{j in nbr(i)} h[j], deg[i] = |nbr(i)| (deg may be NULL): the scatter-add half of
  * MessagePassing.propagate as used by AggConv called on its own (gcn_conv.py:34) */
 int mgv_gather_sum(int H, int64_t N, const float* h, const int32_t* nbr_ptr, const int32_t* nbr_idx,

@@ -1,0 +1,298 @@
+// Linear layers over node rows on bf16x3 split-precision MFMA (mgv_x3.h): the hs_linear / hs_decompose / VAE
+// heads / readout layers of dg_ae_model_aig.py:50-56,100-106 and their input- and weight-gradients.  The fp32
+// kernels of dense.hip price these streaming layers at the fp32-MFMA rate (K=128, M=64: 69 GFLOP per pass);
+// here they are HBM-bound: rows are split into bf16 hi/lo planes in LDS once, the forward keeps its weight
+// fragments in registers for the whole launch, the weight gradient reads both operands transposed from the
+// row-major planes, and the next tile's rows are in flight (registers) while the current tile is multiplied.
+#include "mgv_x3.h"
+#include "../../include/mgvae_hip.h"
+
+namespace mgv {
+
+struct LinX3Args {
+    int64_t N;
+    const float* X1; int K1; int ld1;
+    const float* X2; int K2; int ld2;
+    const __bf16* wpack;    // forward: [2][M*K] = W_hi, W_lo in fragment order (blocks (row tile, k-step))
+    const float* b;
+    float* Y; int ldy;
+    const float* dY; int lddy;
+    float* dW; float* db;
+};
+
+__device__ __forceinline__ float4 f4x(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int M, int K>
+struct LinFwdGeom {
+    using S = WaveSplit<M>;                                   // 4 waves (mgv_common.h)
+    static constexpr int KS = K / 32;
+    static constexpr int LDP = K + 8;                         // bf16 plane row
+    static constexpr int PB = kTileRows * LDP * 2;
+    static constexpr int LDY = M + 4;
+    static constexpr int o_y = 2 * PB;
+    static constexpr int smem_bytes = o_y + kTileRows * LDY * 4;
+    static constexpr int F4 = kTileRows * K / 4;              // float4 per tile
+    static constexpr int PF = F4 / kThreads;
+    static_assert(PF * kThreads == F4 && K % 32 == 0, "tile must split over the threads");
+};
+
+template <int M, int K>
+__global__ __launch_bounds__(kThreads) void k_linear_fwd_x3(LinX3Args a) {
+    using G = LinFwdGeom<M, K>;
+    using S = typename G::S;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* x_hi = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* x_lo = reinterpret_cast<__bf16*>(smem_raw + G::PB);
+    float* s_y = reinterpret_cast<float*>(smem_raw + G::o_y);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int wc = w % S::WPC, wr = w / S::WPC;
+    // this wave's weight fragments: column tiles wc*HCW.., all k-steps, hi and lo
+    bf16x8 wh[S::HCW][G::KS], wl[S::HCW][G::KS];
+    float bias[S::HCW];
+#pragma unroll
+    for (int j = 0; j < S::HCW; ++j) {
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+            const int wo = (((wc * S::HCW + j) * G::KS) + ks) * 512 + lane * 8;
+            wh[j][ks] = ldfrag(a.wpack + wo); wl[j][ks] = ldfrag(a.wpack + M * K + wo);
+        }
+        bias[j] = a.b ? a.b[(wc * S::HCW + j) * 16 + r] : 0.f;
+    }
+    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+    f32x4 pf[G::PF];
+    auto prefetch = [&](int64_t tile) {
+        const int64_t base = tile * kTileRows;
+#pragma unroll
+        for (int u = 0; u < G::PF; ++u) {
+            const int f = tid + u * kThreads;
+            const int row = f / (K / 4), c4 = (f % (K / 4)) * 4;
+            const int64_t node = base + row;
+            if (node < a.N) pf[u] = *reinterpret_cast<const f32x4*>(c4 < a.K1 ? a.X1 + node * a.ld1 + c4 : a.X2 + node * a.ld2 + (c4 - a.K1));
+            else pf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int64_t base = tile * kTileRows;
+#pragma unroll
+        for (int u = 0; u < G::PF; ++u) {
+            const int f = tid + u * kThreads;
+            const int row = f / (K / 4), c4 = (f % (K / 4)) * 4;
+            bf16x4 hi, lo;
+            split4(f4x(pf[u]), hi, lo);
+            st_bf4(x_hi + row * G::LDP + c4, hi); st_bf4(x_lo + row * G::LDP + c4, lo);
+        }
+        lds_barrier();
+        if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+        f32x4 acc[S::RTW][S::HCW];
+#pragma unroll
+        for (int i = 0; i < S::RTW; ++i)
+#pragma unroll
+            for (int j = 0; j < S::HCW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < S::RTW; ++i) {
+                const int off = ((wr * S::RTW + i) * 16 + r) * G::LDP + 32 * ks + 8 * q;
+                const bf16x8 xh = ldfrag(x_hi + off), xl = ldfrag(x_lo + off);
+#pragma unroll
+                for (int j = 0; j < S::HCW; ++j) mma_x3(acc[i][j], xh, xl, wh[j][ks], wl[j][ks]);
+            }
+#pragma unroll
+        for (int i = 0; i < S::RTW; ++i)
+#pragma unroll
+            for (int j = 0; j < S::HCW; ++j) {
+                const int col = (wc * S::HCW + j) * 16 + r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s_y[((wr * S::RTW + i) * 16 + q * 4 + e) * G::LDY + col] = acc[i][j][e] + bias[j];
+            }
+        lds_barrier();
+        for (int i = tid; i < kTileRows * (M / 4); i += kThreads) {
+            const int row = i / (M / 4), c4 = (i % (M / 4)) * 4;
+            const int64_t node = base + row;
+            if (node < a.N) st4(a.Y + node * a.ldy + c4, ld4(s_y + row * G::LDY + c4));
+        }
+        // the planes are rewritten only after this barrier pair; s_y only after the next tile's first barrier
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradient
+// dW[M][K] += dY^T [X1|X2], db[M] += colsum(dY).  NW waves in a WI x WJ grid over the (M/16) x (K/16) output tiles.
+template <int M, int K, int NW, int WI>
+struct LinWgGeom {
+    static constexpr int NT = 64 * NW;
+    static constexpr int TI = M / 16, TJ = K / 16, WJ = NW / WI;
+    static constexpr int ITW = TI / WI, JTW = TJ / WJ;
+    static_assert(ITW * WI == TI && JTW * WJ == TJ && ITW >= 1 && JTW >= 1, "wave grid must tile the output");
+    static constexpr int LDG = M + 8, LDX = K + 8;
+    static constexpr int GPB = kTileRows * LDG * 2, XPB = kTileRows * LDX * 2;
+    static constexpr int F4G = kTileRows * M / 4, F4X = kTileRows * K / 4;
+    static constexpr int PFG = (F4G + NT - 1) / NT, PFX = (F4X + NT - 1) / NT;
+    static_assert(NT % (M / 4) == 0, "a thread must keep its dY column across its loads");
+    static constexpr int o_db = 2 * GPB + 2 * XPB;
+    static constexpr int smem_bytes = o_db + M * 4;
+};
+
+template <int M, int K, int NW, int WI>
+__global__ __launch_bounds__(64 * NW) void k_linear_wgrad_x3(LinX3Args a) {
+    using G = LinWgGeom<M, K, NW, WI>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __bf16* g_hi = reinterpret_cast<__bf16*>(smem_raw);
+    __bf16* g_lo = reinterpret_cast<__bf16*>(smem_raw + G::GPB);
+    __bf16* x_hi = reinterpret_cast<__bf16*>(smem_raw + 2 * G::GPB);
+    __bf16* x_lo = reinterpret_cast<__bf16*>(smem_raw + 2 * G::GPB + G::XPB);
+    float* s_db = reinterpret_cast<float*>(smem_raw + G::o_db);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int it0 = (w / G::WJ) * G::ITW, jt0 = (w % G::WJ) * G::JTW;
+    for (int i = tid; i < M; i += G::NT) s_db[i] = 0.f;
+    f32x4 acc[G::ITW][G::JTW];
+#pragma unroll
+    for (int i = 0; i < G::ITW; ++i)
+#pragma unroll
+        for (int j = 0; j < G::JTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float4 dbs = zero4();            // column sums of dY over this thread's rows (its column quad is fixed)
+    f32x4 pg[G::PFG], px[G::PFX];
+    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+    auto prefetch = [&](int64_t tile) {
+        const int64_t base = tile * kTileRows;
+#pragma unroll
+        for (int u = 0; u < G::PFG; ++u) {
+            const int f = tid + u * G::NT;
+            const int row = f / (M / 4), c4 = (f % (M / 4)) * 4;
+            const int64_t node = base + row;
+            if (f < G::F4G && node < a.N) pg[u] = *reinterpret_cast<const f32x4*>(a.dY + node * a.lddy + c4);
+            else pg[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < G::PFX; ++u) {
+            const int f = tid + u * G::NT;
+            const int row = f / (K / 4), c4 = (f % (K / 4)) * 4;
+            const int64_t node = base + row;
+            if (f < G::F4X && node < a.N) px[u] = *reinterpret_cast<const f32x4*>(c4 < a.K1 ? a.X1 + node * a.ld1 + c4 : a.X2 + node * a.ld2 + (c4 - a.K1));
+            else px[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) prefetch(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+        for (int u = 0; u < G::PFG; ++u) {
+            const int f = tid + u * G::NT;
+            if (f < G::F4G) {
+                const int row = f / (M / 4), c4 = (f % (M / 4)) * 4;
+                const float4 v = f4x(pg[u]);
+                dbs = add4(dbs, v);
+                bf16x4 hi, lo;
+                split4(v, hi, lo);
+                st_bf4(g_hi + row * G::LDG + c4, hi); st_bf4(g_lo + row * G::LDG + c4, lo);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < G::PFX; ++u) {
+            const int f = tid + u * G::NT;
+            if (f < G::F4X) {
+                const int row = f / (K / 4), c4 = (f % (K / 4)) * 4;
+                bf16x4 hi, lo;
+                split4(f4x(px[u]), hi, lo);
+                st_bf4(x_hi + row * G::LDX + c4, hi); st_bf4(x_lo + row * G::LDX + c4, lo);
+            }
+        }
+        lds_barrier();
+        if (tile + gridDim.x < ntiles) prefetch(tile + gridDim.x);
+#pragma unroll
+        for (int ks = 0; ks < kTileRows / 32; ++ks) {
+            bf16x8 bh[G::JTW], bl[G::JTW];
+#pragma unroll
+            for (int j = 0; j < G::JTW; ++j) {
+                bh[j] = ldfrag_tr(x_hi, G::LDX, 32 * ks, (jt0 + j) * 16);
+                bl[j] = ldfrag_tr(x_lo, G::LDX, 32 * ks, (jt0 + j) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < G::ITW; ++i) {
+                const bf16x8 ah = ldfrag_tr(g_hi, G::LDG, 32 * ks, (it0 + i) * 16), al = ldfrag_tr(g_lo, G::LDG, 32 * ks, (it0 + i) * 16);
+#pragma unroll
+                for (int j = 0; j < G::JTW; ++j) mma_x3(acc[i][j], ah, al, bh[j], bl[j]);
+            }
+        }
+        lds_barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < G::ITW; ++i)
+#pragma unroll
+        for (int j = 0; j < G::JTW; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                atomicAdd(a.dW + (int64_t)((it0 + i) * 16 + q * 4 + e) * K + (jt0 + j) * 16 + r, acc[i][j][e]);
+    if (a.db) {
+        if (tid < G::F4G) {              // threads beyond the dY part of a tile never load dY
+            const int c4 = (tid % (M / 4)) * 4;
+            atomicAdd(&s_db[c4 + 0], dbs.x); atomicAdd(&s_db[c4 + 1], dbs.y); atomicAdd(&s_db[c4 + 2], dbs.z); atomicAdd(&s_db[c4 + 3], dbs.w);
+        }
+        __syncthreads();
+        for (int i = tid; i < M; i += G::NT) atomicAdd(a.db + i, s_db[i]);
+    }
+}
+
+template <int M, int K>
+int launch_linear_fwd_x3(const LinX3Args& a, hipStream_t st) {
+    using G = LinFwdGeom<M, K>;
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_fwd_x3<M, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+    int per_cu = 160 * 1024 / G::smem_bytes;
+    per_cu = per_cu > 4 ? 4 : per_cu;
+    hipLaunchKernelGGL((k_linear_fwd_x3<M, K>), dim3(grid_for(ntiles, per_cu)), dim3(kThreads), G::smem_bytes, st, a);
+    MGV_LAUNCH_RET();
+}
+
+template <int M, int K, int NW, int WI>
+int launch_linear_wgrad_x3(const LinX3Args& a, hipStream_t st) {
+    using G = LinWgGeom<M, K, NW, WI>;
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_wgrad_x3<M, K, NW, WI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+    int per_cu = 160 * 1024 / G::smem_bytes;
+    per_cu = per_cu > 2 ? 2 : per_cu;
+    hipLaunchKernelGGL((k_linear_wgrad_x3<M, K, NW, WI>), dim3(grid_for(ntiles, per_cu)), dim3(G::NT), G::smem_bytes, st, a);
+    MGV_LAUNCH_RET();
+}
+
+}  // namespace mgv
+
+extern "C" int mgv_linear_x3_supported(int M, int K) {
+    return (M == 64 && K == 128) || (M == 128 && K == 64) || (M == 64 && K == 64) || (M == 64 && K == 32) || (M == 32 && K == 64) ||
+           (M == 32 && K == 32);
+}
+
+extern "C" int mgv_linear_fwd_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
+                                 const void* wpack_bf16, const float* b, int M, float* Y, int ldy, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && X1 && wpack_bf16 && Y && K1 > 0 && K2 >= 0 && (K2 == 0 || X2));
+    MGV_CHECK_ARG(K1 % 4 == 0 && K2 % 4 == 0 && ld1 >= K1 && ld1 % 4 == 0 && (K2 == 0 || (ld2 >= K2 && ld2 % 4 == 0)) && ldy >= M && ldy % 4 == 0);
+    if (N == 0) return MGV_OK;
+    mgv::LinX3Args a{};
+    a.N = N; a.X1 = X1; a.K1 = K1; a.ld1 = ld1; a.X2 = X2; a.K2 = K2; a.ld2 = ld2; a.wpack = static_cast<const __bf16*>(wpack_bf16);
+    a.b = b; a.Y = Y; a.ldy = ldy;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int K = K1 + K2;
+#define MGV_LF(MM, KK) if (M == MM && K == KK) return mgv::launch_linear_fwd_x3<MM, KK>(a, st);
+    MGV_LF(64, 128) MGV_LF(128, 64) MGV_LF(64, 64) MGV_LF(64, 32) MGV_LF(32, 64) MGV_LF(32, 32)
+#undef MGV_LF
+    return MGV_EUNSUPPORTED;
+}
+
+extern "C" int mgv_linear_wgrad_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
+                                   const float* dY, int lddy, int M, float* dW, float* db, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && X1 && dY && dW && K1 > 0 && K2 >= 0 && (K2 == 0 || X2));
+    MGV_CHECK_ARG(K1 % 4 == 0 && K2 % 4 == 0 && ld1 % 4 == 0 && (K2 == 0 || ld2 % 4 == 0) && lddy % 4 == 0 && lddy >= M);
+    if (N == 0) return MGV_OK;
+    mgv::LinX3Args a{};
+    a.N = N; a.X1 = X1; a.K1 = K1; a.ld1 = ld1; a.X2 = X2; a.K2 = K2; a.ld2 = ld2; a.dY = dY; a.lddy = lddy; a.dW = dW; a.db = db;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int K = K1 + K2;
+#define MGV_WGX(MM, KK, NW, WI) if (M == MM && K == KK) return mgv::launch_linear_wgrad_x3<MM, KK, NW, WI>(a, st);
+    MGV_WGX(64, 128, 8, 2) MGV_WGX(128, 64, 8, 4) MGV_WGX(64, 64, 8, 2) MGV_WGX(64, 32, 8, 4) MGV_WGX(32, 64, 8, 2) MGV_WGX(32, 32, 4, 2)
+#undef MGV_WGX
+    return MGV_EUNSUPPORTED;
+}

@@ -122,6 +122,11 @@ def call(name, *args):
         raise HipLibraryError('%s failed: %s' % (name, _ERR.get(rc, 'hipError_t %d' % rc)))
 
 
+def call_value(name, *args):
+    """Call a query entry point (no stream argument, the return value is the answer, not a status)."""
+    return int(getattr(load(), name)(*args))
+
+
 def check(t, dtype=torch.float32, name='tensor'):
     """Launchers take raw pointers: insist on what they assume."""
     if t is None:

@@ -193,12 +193,31 @@ class StructEncoderFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # Linear over node rows (hs_linear / hs_decompose / VAE heads / readout layers)
 # ------------------------------------------------------------------------------------------------
+_LIN_X3 = {}
+
+
+def _lin_x3(M, K):
+    """Layer shapes served by the bf16x3 linear kernels (the others stay on the fp32 MFMA ones)."""
+    if PRECISION != 'x3':
+        return False
+    key = (int(M), int(K))
+    if key not in _LIN_X3:
+        _LIN_X3[key] = bool(_hip.call_value('mgv_linear_x3_supported', *key))
+    return _LIN_X3[key]
+
+
 def _lin_fwd(x1, x2, W, b, M):
     N, K1 = x1.shape
     K2 = 0 if x2 is None else x2.shape[1]
     check(x1, F32, 'x1'); check(x2, F32, 'x2'); check(W, F32, 'W'); check(b, F32, 'b')
     assert W.shape == (M, K1 + K2)
     y = torch.empty(N, M, dtype=F32, device=x1.device)
+    if _lin_x3(M, K1 + K2):
+        hi, lo = split_bf16(W)
+        wpack = torch.cat([frag_order(hi), frag_order(lo)]).contiguous()
+        _hip.call('mgv_linear_fwd_x3', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
+                  ptr(wpack), ptr(b), M, ptr(y), M)
+        return y
     _hip.call('mgv_linear_fwd', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
               ptr(W), ptr(b), M, ptr(y), M)
     return y
@@ -240,7 +259,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[2] or (ctx.has_b and ctx.needs_input_grad[3]):
             gW = torch.zeros_like(W)
             gb = torch.zeros(M, dtype=F32, device=W.device) if ctx.has_b else None
-            _hip.call('mgv_linear_wgrad', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
+            _hip.call('mgv_linear_wgrad_x3' if _lin_x3(M, K1 + K2) else 'mgv_linear_wgrad', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
                       ptr(gy), gy.stride(0), M, ptr(gW), ptr(gb))
         return gx1, gx2, gW, gb
 
