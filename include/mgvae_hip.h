@@ -82,6 +82,9 @@ int mgv_linear_wgrad(int64_t N, const float* X1, int K1, int ld1, const float* X
  * (M, K = K1 + K2) must be one of the shapes mgv_linear_x3_supported() accepts (the model's layer shapes at H=64/32);
  * forward weights arrive as wpack_bf16[2][M*K] = {W_hi, W_lo} in MFMA fragment order (see mgv_func_sweep_fwd_x3). */
 int mgv_linear_x3_supported(int M, int K);
+/* fragment-order bf16 hi/lo planes (R*K elements each) of the fp32 matrix A = W [R][K] (transpose = 0) or of the
+ * transposed view A[i][k] = W[k][i] (transpose = 1; W is then [K][R]); ldw = leading dimension of W */
+int mgv_wpack_bf16x3(const float* W, int R, int K, int ldw, int transpose, void* hi, void* lo, void* stream);
 int mgv_linear_fwd_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
                       const void* wpack_bf16, const float* b, int M, float* Y, int ldy, void* stream);
 int mgv_linear_wgrad_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,

@@ -235,6 +235,21 @@ __global__ __launch_bounds__(64 * NW) void k_linear_wgrad_x3(LinX3Args a) {
     }
 }
 
+// fp32 matrix -> bf16 hi/lo planes in MFMA fragment order: block (row tile, k-step) = 512 elements, lane 16q+r holds
+// A[16 rt + r][32 ks + 8q .. +7] where A = W (R x K, leading dimension ldw) or its transpose view A[i][k] = W[k][i]
+__global__ __launch_bounds__(256) void k_wpack_bf16x3(const float* W, int R, int K, int ldw, int transpose, __bf16* hi, __bf16* lo) {
+    const int total = R * K, ksn = K / 32;
+    for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
+        const int blk = o >> 9, within = o & 511, lane = within >> 3, e = within & 7;
+        const int rt = blk / ksn, ks = blk % ksn;
+        const int row = rt * 16 + (lane & 15), k = ks * 32 + (lane >> 4) * 8 + e;
+        const float v = transpose ? W[(int64_t)k * ldw + row] : W[(int64_t)row * ldw + k];
+        __bf16 h, l;
+        split_bf16(v, h, l);
+        hi[o] = h; lo[o] = l;
+    }
+}
+
 template <int M, int K>
 int launch_linear_fwd_x3(const LinX3Args& a, hipStream_t st) {
     using G = LinFwdGeom<M, K>;
@@ -254,7 +269,8 @@ int launch_linear_wgrad_x3(const LinX3Args& a, hipStream_t st) {
     if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_wgrad_x3<M, K, NW, WI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
     const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
     int per_cu = 160 * 1024 / G::smem_bytes;
-    per_cu = per_cu > 2 ? 2 : per_cu;
+    const int cap = 1024 / G::NT;                    // 16 waves per CU
+    per_cu = per_cu > cap ? cap : per_cu;
     hipLaunchKernelGGL((k_linear_wgrad_x3<M, K, NW, WI>), dim3(grid_for(ntiles, per_cu)), dim3(G::NT), G::smem_bytes, st, a);
     MGV_LAUNCH_RET();
 }
@@ -295,4 +311,12 @@ extern "C" int mgv_linear_wgrad_x3(int64_t N, const float* X1, int K1, int ld1, 
     MGV_WGX(64, 128, 8, 2) MGV_WGX(128, 64, 8, 4) MGV_WGX(64, 64, 8, 2) MGV_WGX(64, 32, 8, 4) MGV_WGX(32, 64, 8, 2) MGV_WGX(32, 32, 4, 2)
 #undef MGV_WGX
     return MGV_EUNSUPPORTED;
+}
+
+extern "C" int mgv_wpack_bf16x3(const float* W, int R, int K, int ldw, int transpose, void* hi, void* lo, void* stream) {
+    MGV_CHECK_ARG(W && hi && lo && R > 0 && K > 0 && R % 16 == 0 && K % 32 == 0 && ldw >= (transpose ? R : K));
+    const int total = R * K;
+    hipLaunchKernelGGL(mgv::k_wpack_bf16x3, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), W, R, K, ldw, transpose, static_cast<__bf16*>(hi), static_cast<__bf16*>(lo));
+    MGV_LAUNCH_RET();
 }

@@ -40,25 +40,43 @@ def frag_order(w):
     return w.reshape(R // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(-1)
 
 
+def _pack_into(out, off, W, transpose):
+    """bf16 hi/lo fragment-order planes of W (or W^T) at out[off : off + 2 * W.numel()] (one launch)."""
+    R, K = (W.shape[1], W.shape[0]) if transpose else W.shape
+    n = W.numel()
+    if W.dtype != F32 or not W.is_cuda or W.stride(1) != 1:
+        raise HipLibraryError('weight must be an fp32 GPU matrix with contiguous rows')
+    base = out.data_ptr() + 2 * off
+    _hip.call('mgv_wpack_bf16x3', ptr(W), R, K, W.stride(0), int(transpose), _hip.ctypes.c_void_p(base),
+              _hip.ctypes.c_void_p(base + 2 * n))
+    return off + 2 * n
+
+
 def stage_wpack(Wc, Whh):
     """bf16 weight pack of mgv_struct_stage_*_x3: [Wc_hi, Wc_lo, Whh_hi, Whh_lo, WcT_hi, WcT_lo, WhhT_hi, WhhT_lo],
     each block in fragment order."""
-    parts = []
-    for w in (Wc, Whh, Wc.t().contiguous(), Whh.t().contiguous()):
-        hi, lo = split_bf16(w)
-        parts += [frag_order(hi), frag_order(lo)]
-    return torch.cat(parts).contiguous()
+    out = torch.empty(4 * (Wc.numel() + Whh.numel()), dtype=torch.bfloat16, device=Wc.device)
+    off = 0
+    for w, tr in ((Wc, False), (Whh, False), (Wc, True), (Whh, True)):
+        off = _pack_into(out, off, w, tr)
+    return out
 
 
 def sweep_wpack(Wvc):
     """bf16 weight pack of mgv_func_sweep_*_x3 from Wvc [T, 3H, 2H]: per slot [Wvc_hi, Wvc_lo, WvcT_hi, WvcT_lo],
     each block in fragment order."""
-    slots = []
+    out = torch.empty(4 * Wvc.numel(), dtype=torch.bfloat16, device=Wvc.device)
+    off = 0
     for g in range(Wvc.shape[0]):
-        for w in (Wvc[g], Wvc[g].t().contiguous()):
-            hi, lo = split_bf16(w)
-            slots += [frag_order(hi), frag_order(lo)]
-    return torch.cat(slots).contiguous()
+        off = _pack_into(out, off, Wvc[g], False)
+        off = _pack_into(out, off, Wvc[g], True)
+    return out
+
+
+def linear_wpack(W):
+    out = torch.empty(2 * W.numel(), dtype=torch.bfloat16, device=W.device)
+    _pack_into(out, 0, W, False)
+    return out
 
 
 def _zeros_like_params(*ts):
@@ -206,18 +224,20 @@ def _lin_x3(M, K):
     return _LIN_X3[key]
 
 
-def _lin_fwd(x1, x2, W, b, M):
+def _lin_fwd(x1, x2, W, b, M, wpack=None):
+    """wpack given: W is ignored (bf16x3 path with a ready fragment-order pack)."""
     N, K1 = x1.shape
     K2 = 0 if x2 is None else x2.shape[1]
-    check(x1, F32, 'x1'); check(x2, F32, 'x2'); check(W, F32, 'W'); check(b, F32, 'b')
-    assert W.shape == (M, K1 + K2)
+    check(x1, F32, 'x1'); check(x2, F32, 'x2'); check(b, F32, 'b')
     y = torch.empty(N, M, dtype=F32, device=x1.device)
-    if _lin_x3(M, K1 + K2):
-        hi, lo = split_bf16(W)
-        wpack = torch.cat([frag_order(hi), frag_order(lo)]).contiguous()
+    if wpack is not None or _lin_x3(M, K1 + K2):
+        if wpack is None:
+            wpack = linear_wpack(check(W, F32, 'W'))
         _hip.call('mgv_linear_fwd_x3', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
                   ptr(wpack), ptr(b), M, ptr(y), M)
         return y
+    check(W, F32, 'W')
+    assert W.shape == (M, K1 + K2)
     _hip.call('mgv_linear_fwd', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
               ptr(W), ptr(b), M, ptr(y), M)
     return y
@@ -252,10 +272,16 @@ class LinearFn(torch.autograd.Function):
         K2 = 0 if x2 is None else x2.shape[1]
         M = W.shape[0]
         gx1 = gx2 = gW = gb = None
+        def dgrad(Ws, Kx):         # gy [N, M] x Ws [M, Kx]: the transposed weight view is packed straight from W
+            if _lin_x3(Kx, M):
+                pack = torch.empty(2 * Ws.numel(), dtype=torch.bfloat16, device=W.device)
+                _pack_into(pack, 0, Ws, True)
+                return _lin_fwd(gy, None, None, None, Kx, wpack=pack)
+            return _lin_fwd(gy, None, Ws.t().contiguous(), None, Kx)
         if ctx.needs_input_grad[0]:
-            gx1 = _lin_fwd(gy, None, W[:, :K1].t().contiguous(), None, K1)
+            gx1 = dgrad(W[:, :K1], K1)
         if x2 is not None and ctx.needs_input_grad[1]:
-            gx2 = _lin_fwd(gy, None, W[:, K1:].t().contiguous(), None, K2)
+            gx2 = dgrad(W[:, K1:], K2)
         if ctx.needs_input_grad[2] or (ctx.has_b and ctx.needs_input_grad[3]):
             gW = torch.zeros_like(W)
             gb = torch.zeros(M, dtype=F32, device=W.device) if ctx.has_b else None
