@@ -171,6 +171,22 @@ int mgv_recon_loss_bwd(int H, int64_t N, const float* s, const float* t, int ld,
                        int64_t Epos, const int32_t* pos_out_ptr, const int32_t* pos_out_dst, const int32_t* pos_in_ptr,
                        const int32_t* pos_in_src, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
                        const float* gscale, float* ds, float* dt, void* stream);
+/* the same gradient when BOTH edge sets come as CSR pairs (by source and by destination; the negatives bucketed by
+ * mgv_neg_bucket): ds/dt are WRITTEN, every row once, no atomics and no zero fill */
+int mgv_recon_loss_bwd_csr(int H, int64_t N, const float* s, const float* t, int ld, const int32_t* pos_out_ptr,
+                           const int32_t* pos_out_dst, const int32_t* pos_in_ptr, const int32_t* pos_in_src, int64_t Epos,
+                           const int32_t* neg_out_ptr, const int32_t* neg_out_dst, const int32_t* neg_in_ptr,
+                           const int32_t* neg_in_src, int64_t Eneg, const float* gscale, float* ds, float* dt, void* stream);
+/* negative sampling of the reconstruction loss (dg_ae_model_aig.py:115-119, torch_geometric negative_sampling): E pairs
+ * uniform over {(u, v): u != v, (u, v) not an edge of the CSR}, from a counter-based generator (seed); cnt_out/cnt_in
+ * [N] (zeroed by the caller) receive the pairs' per-source / per-destination counts.  mgv_neg_bucket then buckets the
+ * pairs: out_ptr/in_ptr = exclusive scans of the counts ([N+1]), cur_* = zeroed [N] cursors; outputs the pairs
+ * grouped by source (srt_src, srt_dst: int64 like edge_index rows), out_dst[E] and in_src[E] (int32 CSR payloads). */
+int mgv_neg_sample(int64_t N, int64_t E, uint64_t seed, const int32_t* pos_out_ptr, const int32_t* pos_out_dst,
+                   int64_t* neg_src, int64_t* neg_dst, int32_t* cnt_out, int32_t* cnt_in, void* stream);
+int mgv_neg_bucket(int64_t E, const int64_t* neg_src, const int64_t* neg_dst, const int32_t* out_ptr, const int32_t* in_ptr,
+                   int32_t* cur_out, int32_t* cur_in, int64_t* srt_src, int64_t* srt_dst, int32_t* out_dst, int32_t* in_src,
+                   void* stream);
 
 /* ---- functional-similarity loss (trainer.py:158-163, utils/utils.py:32-36): dis = 1 - cos(hf[a], hf[b]),
  * L1 between the z-normalised dis and z-normalised tt.  ws[8] doubles (zeroed by the caller):

@@ -148,6 +148,51 @@ __global__ __launch_bounds__(kThreads) void k_recon_bwd_pull(int64_t N, const fl
     }
 }
 
+// Both halves of the loss from CSRs (positives = the batch graph, negatives bucketed by mgv_neg_bucket): every
+// output row is WRITTEN once, no zero fill, no atomics.
+template <int H>
+__global__ __launch_bounds__(kThreads) void k_recon_bwd_pull2(int64_t N, const float* s, const float* t, int ld,
+                                                              const int32_t* pout_ptr, const int32_t* pout_dst, const int32_t* pin_ptr,
+                                                              const int32_t* pin_src, int64_t Ep, const int32_t* nout_ptr,
+                                                              const int32_t* nout_dst, const int32_t* nin_ptr, const int32_t* nin_src,
+                                                              int64_t En, const float* gscale, float* ds, float* dt) {
+    constexpr int LPR = H / 4, RPB = kThreads / LPR;
+    const int lr = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+    const float wp = Ep > 0 ? -(*gscale) / (float)Ep : 0.f, wn = En > 0 ? (*gscale) / (float)En : 0.f;
+    for (int64_t n0 = (int64_t)blockIdx.x * RPB; n0 < N; n0 += (int64_t)gridDim.x * RPB) {
+        const int64_t u = n0 + slot;
+        if (u >= N) continue;
+        const float4 su = ld4(s + u * ld + 4 * lr), tu = ld4(t + u * ld + 4 * lr);
+        float4 gs = zero4(), gt = zero4();
+        if (Ep > 0) {
+            for (int e = pout_ptr[u]; e < pout_ptr[u + 1]; ++e) {
+                const float4 tv = ld4(t + (int64_t)pout_dst[e] * ld + 4 * lr);
+                const float p = sigmoidf_(group_sum<LPR>(dot4(su, tv)));
+                gs = fma4(wp * p * (1.0f - p) / (p + 1e-15f), tv, gs);
+            }
+            for (int e = pin_ptr[u]; e < pin_ptr[u + 1]; ++e) {
+                const float4 sv = ld4(s + (int64_t)pin_src[e] * ld + 4 * lr);
+                const float p = sigmoidf_(group_sum<LPR>(dot4(sv, tu)));
+                gt = fma4(wp * p * (1.0f - p) / (p + 1e-15f), sv, gt);
+            }
+        }
+        if (En > 0) {
+            for (int e = nout_ptr[u]; e < nout_ptr[u + 1]; ++e) {
+                const float4 tv = ld4(t + (int64_t)nout_dst[e] * ld + 4 * lr);
+                const float p = sigmoidf_(group_sum<LPR>(dot4(su, tv)));
+                gs = fma4(wn * p * (1.0f - p) / ((1.0f - p) + 1e-15f), tv, gs);
+            }
+            for (int e = nin_ptr[u]; e < nin_ptr[u + 1]; ++e) {
+                const float4 sv = ld4(s + (int64_t)nin_src[e] * ld + 4 * lr);
+                const float p = sigmoidf_(group_sum<LPR>(dot4(sv, tu)));
+                gt = fma4(wn * p * (1.0f - p) / ((1.0f - p) + 1e-15f), sv, gt);
+            }
+        }
+        st4(ds + u * ld + 4 * lr, gs);
+        st4(dt + u * ld + 4 * lr, gt);
+    }
+}
+
 // Arbitrary edge lists (the sampled negatives): one edge per H-lane group, one float per lane, so every
 // atomic wave-instruction adds whole contiguous rows (the shape the memory-side atomic units like).
 template <int H>
@@ -397,6 +442,21 @@ extern "C" int mgv_recon_loss_bwd(int H, int64_t N, const float* s, const float*
             default: return MGV_EUNSUPPORTED;
         }
     }
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_recon_loss_bwd_csr(int H, int64_t N, const float* s, const float* t, int ld, const int32_t* pos_out_ptr,
+                                      const int32_t* pos_out_dst, const int32_t* pos_in_ptr, const int32_t* pos_in_src, int64_t Epos,
+                                      const int32_t* neg_out_ptr, const int32_t* neg_out_dst, const int32_t* neg_in_ptr,
+                                      const int32_t* neg_in_src, int64_t Eneg, const float* gscale, float* ds, float* dt, void* stream) {
+    MGV_CHECK_ARG(s && t && gscale && ds && dt && Epos >= 0 && Eneg >= 0 && N >= 0 && ld >= H && ld % 4 == 0);
+    MGV_CHECK_ARG(Epos == 0 || (pos_out_ptr && pos_out_dst && pos_in_ptr && pos_in_src));
+    MGV_CHECK_ARG(Eneg == 0 || (neg_out_ptr && neg_out_dst && neg_in_ptr && neg_in_src));
+    if (N == 0) return MGV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_recon_bwd_pull2<HH>), dim3(mgv::items_grid(N, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st,
+                                         N, s, t, ld, pos_out_ptr, pos_out_dst, pos_in_ptr, pos_in_src, Epos, neg_out_ptr, neg_out_dst,
+                                         neg_in_ptr, neg_in_src, Eneg, gscale, ds, dt));
     MGV_LAUNCH_RET();
 }
 

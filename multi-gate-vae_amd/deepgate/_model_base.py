@@ -13,9 +13,10 @@ from .arch.mlp import MLP
 from .arch.tfmlp import TFMlpAggr
 from .data import plan_of
 from .digae_layer import DirectedInnerProductDecoder
-from .sampling import negative_sampling
+from .sampling import NegativeEdges, negative_sampling, negative_sampling_device
 
 EPS = 1e-15
+DEVICE_SAMPLER = os.environ.get('MGV_NEG_SAMPLER', 'device') != 'torch'
 MAX_LOGSTD = 10
 
 
@@ -70,11 +71,16 @@ class FunctionalModel(nn.Module):
         """`plan` (optional): the batch's GraphPlan when pos_edge_index is the batch's own edge set (any
         order) — the positive half of the backward then needs no atomics."""
         st = ops.linear(hs, self.hs_decompose.weight, self.hs_decompose.bias)
-        if neg_edge_index is None:
-            neg_edge_index = negative_sampling(pos_edge_index, hs.shape[0], keys=edge_keys)
         if plan is not None and (plan.E != pos_edge_index.shape[1] or plan.N != hs.shape[0]):
             plan = None
-        loss, counts, pred_bin = ops.ReconLossFn.apply(st, pos_edge_index, neg_edge_index, want_pred, plan)
+        neg_csr = None
+        if neg_edge_index is None:
+            # with the batch's plan: fused device sampler, pairs bucketed for an atomic-free backward
+            neg_edge_index = negative_sampling_device(plan) if plan is not None and hs.is_cuda and hs.shape[0] >= 2 and DEVICE_SAMPLER \
+                else negative_sampling(pos_edge_index, hs.shape[0], keys=edge_keys)
+        if isinstance(neg_edge_index, NegativeEdges):
+            neg_csr, neg_edge_index = neg_edge_index.csr, neg_edge_index.edge_index
+        loss, counts, pred_bin = ops.ReconLossFn.apply(st, pos_edge_index, neg_edge_index, want_pred, plan, neg_csr)
         self.last_confusion = counts        # {TP, FP, TN, FN} on device, no host copy needed for metrics
         Ep, En = pos_edge_index.shape[1], neg_edge_index.shape[1]
         gt_bin = None

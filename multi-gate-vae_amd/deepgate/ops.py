@@ -441,8 +441,10 @@ class ReconLossFn(torch.autograd.Function):
     on request, pred_bin."""
 
     @staticmethod
-    def forward(ctx, st, pos_edge_index, neg_edge_index, want_pred, plan=None):
-        """`plan`: GraphPlan whose edges are exactly pos_edge_index (any order) -> atomic-free positive half."""
+    def forward(ctx, st, pos_edge_index, neg_edge_index, want_pred, plan=None, neg_csr=None):
+        """`plan`: GraphPlan whose edges are exactly pos_edge_index (any order) -> atomic-free positive half;
+        `neg_csr`: (out_ptr, out_dst, in_ptr, in_src) over neg_edge_index (sampling.NegativeEdges) -> atomic-free
+        negative half as well."""
         std = check(st.detach().contiguous(), F32, 'st')
         N, H2 = std.shape
         H = H2 // 2
@@ -458,7 +460,7 @@ class ReconLossFn(torch.autograd.Function):
                   ptr(sums), ptr(counts), ptr(pred))
         loss = (sums[0] / max(Ep, 1) + sums[1] / max(En, 1)).to(F32)
         ctx.save_for_backward(std, ps, pd, ns, nd)
-        ctx.plan = plan
+        ctx.plan, ctx.neg_csr = plan, neg_csr
         ctx.mark_non_differentiable(counts)
         if pred is not None:
             ctx.mark_non_differentiable(pred)
@@ -470,13 +472,19 @@ class ReconLossFn(torch.autograd.Function):
         std, ps, pd, ns, nd = ctx.saved_tensors
         H2 = std.shape[1]
         H = H2 // 2
-        dst_ = torch.zeros_like(std)
         g = gloss.detach().to(F32).reshape(1).contiguous()
         pl = ctx.plan
+        if pl is not None and ctx.neg_csr is not None:
+            dst_ = torch.empty_like(std)
+            _hip.call('mgv_recon_loss_bwd_csr', H, std.shape[0], ptr(std), ptr(std[:, H:]), H2, ptr(pl.out_ptr), ptr(pl.out_dst),
+                      ptr(pl.in_ptr), ptr(pl.in_src), ps.numel(), *[ptr(c) for c in ctx.neg_csr], ns.numel(), ptr(g), ptr(dst_),
+                      ptr(dst_[:, H:]))
+            return dst_, None, None, None, None, None
+        dst_ = torch.zeros_like(std)
         csr = (pl.out_ptr, pl.out_dst, pl.in_ptr, pl.in_src) if pl is not None else (None, None, None, None)
         _hip.call('mgv_recon_loss_bwd', H, std.shape[0], ptr(std), ptr(std[:, H:]), H2, ptr(ps), ptr(pd), ps.numel(),
                   *[ptr(c) for c in csr], ptr(ns), ptr(nd), ns.numel(), ptr(g), ptr(dst_), ptr(dst_[:, H:]))
-        return dst_, None, None, None, None
+        return dst_, None, None, None, None, None
 
 
 def confusion_counts(pred_bin, gt_bin):

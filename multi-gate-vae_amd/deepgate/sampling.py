@@ -4,8 +4,53 @@ The reference calls `torch_geometric.utils.negative_sampling(pos ∪ self-loops,
 (dg_ae_model_aig.py:115-119): as many (src, dst) pairs as that edge set has, drawn uniformly from the
 pairs that are neither an existing edge nor a self loop (pairs may cross graphs of a batch).  Same
 distribution here, from rejection sampling on the device with torch index ops (the pairs feed the
-HIP recon-loss kernel; SURVEY.md §8f row 3 lists a fused sampler as follow-up work)."""
+HIP recon-loss kernel), or — when the batch's GraphPlan is at hand — from the fused device sampler
+(`negative_sampling_device`, csrc/neg_sample.hip), which also buckets the pairs by source and by destination so
+that the loss gradient needs no atomics."""
+import itertools
+
 import torch
+
+from . import _hip
+from ._hip import ptr
+
+_CALLS = itertools.count()
+
+
+class NegativeEdges:
+    """Sampled negative pairs grouped by source: `edge_index` [2, E] int64 plus the two int32 CSRs over them."""
+
+    def __init__(self, edge_index, out_ptr, out_dst, in_ptr, in_src):
+        self.edge_index, self.out_ptr, self.out_dst, self.in_ptr, self.in_src = edge_index, out_ptr, out_dst, in_ptr, in_src
+
+    @property
+    def csr(self):
+        return self.out_ptr, self.out_dst, self.in_ptr, self.in_src
+
+
+def negative_sampling_device(plan, num_neg_samples=None, generator=None):
+    """Same distribution as `negative_sampling` (uniform over non-edges that are not self loops, with replacement),
+    drawn by one kernel from a counter-based generator seeded from torch's seed and a call counter (no host sync)."""
+    N, dev = plan.N, plan.device
+    if getattr(plan, 'num_self_loops', None) is None:
+        dst_of = plan.out_dst.long()
+        src_of = torch.repeat_interleave(torch.arange(N, device=dev), (plan.out_ptr[1:] - plan.out_ptr[:-1]).long())
+        plan.num_self_loops = int((dst_of == src_of).sum().item())
+    E = (plan.E - plan.num_self_loops) + N if num_neg_samples is None else int(num_neg_samples)
+    base = generator.initial_seed() if generator is not None else torch.initial_seed()
+    seed = (base * 0x9E3779B97F4A7C15 + next(_CALLS) * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
+    scratch = torch.zeros(4, N, dtype=torch.int32, device=dev)          # counts by source / destination, bucket cursors
+    neg = torch.empty(2, E, dtype=torch.int64, device=dev)
+    _hip.call('mgv_neg_sample', N, E, seed, ptr(plan.out_ptr), ptr(plan.out_dst), ptr(neg[0]), ptr(neg[1]), ptr(scratch[0]), ptr(scratch[1]))
+    ptrs = torch.zeros(2, N + 1, dtype=torch.int32, device=dev)
+    for k in range(2):                 # 1-D scans (the device-wide scan; the batched innermost-dim kernel is ~100x slower here)
+        ptrs[k, 1:] = torch.cumsum(scratch[k], 0, dtype=torch.int32)
+    srt = torch.empty(2, E, dtype=torch.int64, device=dev)
+    out_dst = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    in_src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    _hip.call('mgv_neg_bucket', E, ptr(neg[0]), ptr(neg[1]), ptr(ptrs[0]), ptr(ptrs[1]), ptr(scratch[2]), ptr(scratch[3]),
+              ptr(srt[0]), ptr(srt[1]), ptr(out_dst), ptr(in_src))
+    return NegativeEdges(srt, ptrs[0], out_dst, ptrs[1], in_src)
 
 
 def sorted_edge_keys(pos_edge_index, num_nodes):

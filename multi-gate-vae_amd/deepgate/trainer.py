@@ -149,7 +149,8 @@ class Trainer():
         hs, hf = self.model(batch)
         neg = getattr(batch, 'neg_edge_index', None)
         keys = None
-        if neg is None:                      # sorted edge keys for the rejection sampler: static per batch
+        if neg is None and getattr(batch, '_mgv_plan', None) is None:
+            # no plan (hence no device sampler): sorted edge keys for the torch rejection sampler, static per batch
             keys = getattr(batch, '_mgv_edge_keys', None)
             if keys is None:
                 keys = batch._mgv_edge_keys = sorted_edge_keys(batch.edge_index, batch.num_nodes)
