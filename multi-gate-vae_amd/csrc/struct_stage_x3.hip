@@ -504,6 +504,41 @@ __device__ __forceinline__ void wgrad_flush_x3(const f32x4 (&acc)[WgradX3<H>::TP
     }
 }
 
+// H = 64 with 8 waves: the LDS read rate bounds the weight gradient, so every wave owns a 2x2 block of output tiles
+// of ONE matrix (waves 0-3: Wc against the aggregate planes, waves 4-7: Whh against the own-row planes) and reuses
+// each transposed fragment twice: 8 fragment reads per 12 MFMA triples instead of 12.
+template <int H>
+__device__ __forceinline__ void wgrad_blk_x3(f32x4 (&acc)[4], const __bf16* d_hi, const __bf16* d_lo, const __bf16* x_hi, const __bf16* x_lo) {
+    constexpr int LDP = H + 8;
+    const int b = (threadIdx.x >> 6) & 3;
+    const int it0 = 2 * (b >> 1), jt0 = 2 * (b & 1);
+#pragma unroll 1
+    for (int kk = 0; kk < kTileRows / 32; ++kk) {
+        const int k0 = 32 * kk;
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr(x_hi, LDP, k0, (jt0 + j) * 16); bl[j] = ldfrag_tr(x_lo, LDP, k0, (jt0 + j) * 16); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16x8 ah = ldfrag_tr(d_hi, LDP, k0, (it0 + i) * 16), al = ldfrag_tr(d_lo, LDP, k0, (it0 + i) * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma_x3(acc[i * 2 + j], ah, al, bh[j], bl[j]);
+        }
+    }
+}
+
+template <int H>
+__device__ __forceinline__ void wgrad_blk_flush_x3(const f32x4 (&acc)[4], float* dW) {
+    const int lane = threadIdx.x & 63, b = (threadIdx.x >> 6) & 3, r = lane & 15, q = lane >> 4;
+    const int it0 = 2 * (b >> 1), jt0 = 2 * (b & 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(dW + (int64_t)((it0 + i) * 16 + q * 4 + e) * H + (jt0 + j) * 16 + r, acc[i * 2 + j][e]);
+}
+
 __device__ __forceinline__ void colsum_lds_x3(float v, float* dst) {
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -541,11 +576,18 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
     const bool need_dgrad = a.g_direct_out != nullptr;
     const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
 
-    f32x4 gWc[3][W::TPW], gWhh[3][W::TPW];
+    // weight-gradient accumulators, persistent over the workgroup's tiles.  WBLK (H = 64): gWc[g] holds the wave's 2x2
+    // block of ITS matrix (gWhh unused); otherwise TPW tiles of each matrix per wave.
+    constexpr bool WBLK = (H == 64 && kNW == 8 && kTPR == 2);
+    constexpr int GT = WBLK ? 4 : W::TPW;
+    f32x4 gWc[3][GT], gWhh[3][WBLK ? 1 : W::TPW];
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < 3; ++g) {
 #pragma unroll
-        for (int t = 0; t < W::TPW; ++t) { gWc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f}; gWhh[g][t] = gWc[g][t]; }
+        for (int t = 0; t < GT; ++t) gWc[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < (WBLK ? 1 : W::TPW); ++t) gWhh[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // bias-type gradients (dbc, dxtab, dbhh) as one more wgrad tile per pass: dG^T x [deg, onehot(cls), 1]
     f32x4 gX[4];
 #pragma unroll
@@ -756,8 +798,16 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                 const int g = p < 2 ? p : 2;
                 const __bf16* ph = d_hi + t2 * 2 * kTileRows * LDP;
                 const __bf16* pl = ph + kTileRows * LDP;
-                if (p != 3) wgrad_x3<H>(gWc[g], ph, pl, agg_hi, agg_lo);
-                if (p != 2) wgrad_x3<H>(gWhh[g], ph, pl, hin_hi, hin_lo);
+                if constexpr (WBLK) {
+                    // round 0 (r, z gates): both matrices take the tile; round 1: Wc takes the n-input tile (t2 = 0), Whh the
+                    // n-hidden tile (t2 = 1), each from its own wave group in ONE pass
+                    const bool whh = w >= 4;
+                    if (rnd == 0) wgrad_blk_x3<H>(gWc[g], ph, pl, whh ? hin_hi : agg_hi, whh ? hin_lo : agg_lo);
+                    else if (t2 == (whh ? 1 : 0)) wgrad_blk_x3<H>(gWc[2], ph, pl, whh ? hin_hi : agg_hi, whh ? hin_lo : agg_lo);
+                } else {
+                    if (p != 3) wgrad_x3<H>(gWc[g], ph, pl, agg_hi, agg_lo);
+                    if (p != 2) wgrad_x3<H>(gWhh[g], ph, pl, hin_hi, hin_lo);
+                }
                 if (w < H / 16) {          // wave-uniform: gate-column tile w of the bias-type gradients
 #pragma unroll
                     for (int ks = 0; ks < kTileRows / 32; ++ks)
@@ -800,8 +850,12 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
     STAMP_FLUSH(a);
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-        wgrad_flush_x3<H>(gWc[g], a.dWc + (int64_t)g * H * H);
-        wgrad_flush_x3<H>(gWhh[g], a.dWhh + (int64_t)g * H * H);
+        if constexpr (WBLK) {
+            wgrad_blk_flush_x3<H>(gWc[g], (w >= 4 ? a.dWhh : a.dWc) + (int64_t)g * H * H);
+        } else {
+            wgrad_flush_x3<H>(gWc[g], a.dWc + (int64_t)g * H * H);
+            wgrad_flush_x3<H>(gWhh[g], a.dWhh + (int64_t)g * H * H);
+        }
     }
     if (w < H / 16) {
         // gX[p][e] = sum_rows dG_p[row][i] * Xe[row][j] with i = 16w + 4q + e, j = r:
