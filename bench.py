@@ -32,7 +32,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, fp32-input matrix peak (
 PEAK_HBM_GBPS = 8000.0           # HBM3E spec (6.3 TB/s is what a streaming copy reaches)
 
 
-def cpu_baseline(cfg, H, rounds, seed_sd, graphs=2):
+def cpu_baseline(cfg, H, rounds, seed_sd, graphs=4):
     """Oracle train step (oracle/ref_cpu.py, O(edges) sweep) on `graphs` graphs of the workload — a
     bounded sample — on the host cores this process may use (capped at the box's 16-core share)."""
     from deepgate import synthetic as syn
@@ -150,20 +150,24 @@ def main():
         order = sorted(summ.items(), key=lambda kv: -kv[1][1])
         for name, (calls, ms) in order:
             print('  %-24s %6d calls %10.3f ms total %9.3f ms/call' % (name, calls, ms, ms / max(calls, 1)), file=sys.stderr)
-        dom, (calls, ms) = order[0]
-        per_launch_s = ms / calls * 1e-3
+        dom = order[0][0]
+        # full-size launches only: the first half round of each encoder runs the same kernel on a (degree, class)
+        # table of a few rows, which must not dilute the per-launch average the roofline is priced on
+        times = _hip.profile_times(table, dom)
+        full = [t for t in times if t >= 0.5 * max(times)]
+        per_launch_s = sum(full) / len(full) * 1e-3
         # algorithmic cost of one launch: rows gathered/streamed once, fp32 storage
         fl = {'mgv_struct_stage_bwd': 36.0 * H * H * N, 'mgv_struct_stage_fwd': 12.0 * H * H * N,
               'mgv_struct_stage_bwd_x3': 36.0 * H * H * N, 'mgv_struct_stage_fwd_x3': 12.0 * H * H * N}.get(dom)
         by = {'mgv_struct_stage_bwd': 4.0 * H * (2 * E + 4 * N) + 8.0 * (N + E), 'mgv_struct_stage_fwd': 4.0 * H * (E + 2 * N) + 4.0 * (2 * N + E),
               'mgv_struct_stage_bwd_x3': 4.0 * H * (2 * E + 4 * N) + 8.0 * (N + E),
               'mgv_struct_stage_fwd_x3': 4.0 * H * (E + 2 * N) + 4.0 * (2 * N + E)}.get(dom)
-        roof = {'kernel': dom, 'launch_ms': per_launch_s * 1e3, 'traffic': None}
+        roof = {'kernel': dom, 'launch_ms': per_launch_s * 1e3, 'launches_averaged': len(full), 'traffic': None}
         try:        # HBM bytes per launch from the committed PMC passes (same workload only)
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_x3_pmc_traffic.json')))
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
             if pmc.get('N') == N and dom in pmc['kernels']:
                 roof['traffic'] = pmc['kernels'][dom]['hbm_bytes_per_launch']
-                roof['traffic_source'] = 'profiles/r01_x3_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)'
+                roof['traffic_source'] = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)'
         except (OSError, ValueError, KeyError):
             pass
         if dom.endswith('_x3') and by is not None:

@@ -107,6 +107,12 @@ def profile_summary(table):
     return {k: (len(v), sum(s.elapsed_time(e) for s, e in v)) for k, v in (table or {}).items()}
 
 
+def profile_times(table, name):
+    """Per-call device times (ms) of one launcher; synchronises."""
+    torch.cuda.synchronize()
+    return [s.elapsed_time(e) for s, e in (table or {}).get(name, [])]
+
+
 def call(name, *args):
     """Call launcher `name`; the current torch stream is appended as the last argument."""
     lib = load()
