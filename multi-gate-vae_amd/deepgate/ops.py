@@ -216,7 +216,7 @@ _LIN_X3 = {}
 
 def _lin_x3(M, K):
     """Layer shapes served by the bf16x3 linear kernels (the others stay on the fp32 MFMA ones)."""
-    if PRECISION != 'x3':
+    if PRECISION != 'x3' or os.environ.get('MGV_LIN_X3', '1') == '0':
         return False
     key = (int(M), int(K))
     if key not in _LIN_X3:
@@ -344,7 +344,7 @@ class FuncSweepFn(torch.autograd.Function):
         assert plan.has_levels and plan.num_slots == T and plan.N == N
         hf = torch.zeros(N, H, dtype=F32, device=hsd.device)
         ltp = (_hip.ctypes.c_int32 * len(plan.level_tile_ptr))(*plan.level_tile_ptr)
-        wpack = sweep_wpack(par[1]) if use_x3(H) else None
+        wpack = sweep_wpack(par[1]) if (use_x3(H) and os.environ.get('MGV_SWEEP_X3', '1') != '0') else None
         if wpack is not None:
             _hip.call('mgv_func_sweep_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.order_span),
                       ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
