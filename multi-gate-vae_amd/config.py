@@ -28,6 +28,10 @@ def get_parse_args(argv=None):
                         help='train on N synthetic levelised graphs of --type instead of the npz dataset')
     parser.add_argument('--synthetic_nodes', type=int, default=1024, help='nodes per synthetic graph')
     parser.add_argument('--synthetic_levels', type=int, default=30, help='logic levels per synthetic graph')
+    parser.add_argument('--data_dir', type=str, default='', help='directory with graphs.npz (and labels.npz for mig/xag/xmg): '
+                        'the reference hard-codes it in train.py')
+    parser.add_argument('--circuit_file', type=str, default='graphs.npz')
+    parser.add_argument('--label_file', type=str, default='labels.npz')
     parser.add_argument('--stage_epochs', type=int, nargs=3, default=[100, 60, 60],
                         help='epochs of the three training stages (train.py:81-85)')
     parser.add_argument('--save_dir', type=str, default='./exp')

@@ -8,6 +8,7 @@ from . import dg_ae_model_aig, dg_ae_model_mig, dg_ae_model_xmg, dg_ae_model_xag
 from .dg_ae_model_xag import Model  # noqa: F401
 from .trainer import Trainer, GraphLoader  # noqa: F401
 from .data import CircuitBatch  # noqa: F401
+from .parser import NpzParser  # noqa: F401
 from .graph_plan import GraphPlan  # noqa: F401
 from .optim import FlatAdam  # noqa: F401
 from .utils import zero_normalization, AverageMeter  # noqa: F401

@@ -118,8 +118,8 @@ def collate(graphs):
     (`parser_func.py:28-40`): every key containing "index" is offset by the running node count and
     edge/pair indices concatenate along dim 1; levels are NOT offset."""
     off = 0
-    acc = {k: [] for k in ('x', 'edge_index', 'gate', 'forward_level', 'forward_index', 'prob',
-                           'tt_pair_index', 'tt_sim', 'neg_edge_index')}
+    keys = ('x', 'edge_index', 'gate', 'forward_level', 'forward_index', 'prob', 'tt_pair_index', 'tt_sim', 'neg_edge_index')
+    acc = {k: [] for k in keys if all(k in g for g in graphs)}      # dataset graphs carry no fixed negatives
     graph_ptr = [0]
     for g in graphs:
         for k in acc:

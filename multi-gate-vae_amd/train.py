@@ -5,8 +5,8 @@ Trainer, then the three-stage loss-weight schedule [1,0,0] -> [1,5,0] -> [1,4,4]
     torchrun --nproc_per_node=8 --master-addr 127.0.0.1 train.py ... --distributed
 
 The reference hard-codes the authors' dataset directory and `distributed=True`; here `--distributed`
-is honoured and `--synthetic N` generates N levelised DAGs (the npz dataset loader is follow-up work,
-SURVEY.md §8f row 2)."""
+is honoured, `--data_dir` points at the MixGate npz files (deepgate.NpzParser) and `--synthetic N` generates N
+levelised DAGs instead."""
 import os
 
 import deepgate
@@ -26,13 +26,18 @@ def main(argv=None):
         'xmg': deepgate.dg_ae_model_xmg.Model, 'xag': deepgate.dg_ae_model_xag.Model,
     }
     print('[INFO] Parse Dataset')
-    if args.synthetic <= 0:
-        raise SystemExit('the npz dataset of the reference is not available here: pass --synthetic N')
-    n_in = max(args.synthetic_nodes // 16, 1)
-    graphs = [synthetic.make_graph(args.type, args.synthetic_nodes, args.synthetic_levels, 100 + i, n_inputs=n_in)
-              for i in range(args.synthetic)]
-    cut = max(int(len(graphs) * 0.9), 1)
-    train_dataset, val_dataset = graphs[:cut], graphs[cut:]
+    if args.synthetic > 0:
+        n_in = max(args.synthetic_nodes // 16, 1)
+        graphs = [synthetic.make_graph(args.type, args.synthetic_nodes, args.synthetic_levels, 100 + i, n_inputs=n_in)
+                  for i in range(args.synthetic)]
+        cut = max(int(len(graphs) * 0.9), 1)
+        train_dataset, val_dataset = graphs[:cut], graphs[cut:]
+    elif args.data_dir:
+        dataset = deepgate.NpzParser(args.data_dir, os.path.join(args.data_dir, args.circuit_file),
+                                     os.path.join(args.data_dir, args.label_file), args.type)
+        train_dataset, val_dataset = dataset.get_dataset()
+    else:
+        raise SystemExit('pass --data_dir DIR (graphs.npz [+ labels.npz]) or --synthetic N')
 
     print('[INFO] Create Model')
     if 'DG' not in args.model:
