@@ -181,7 +181,9 @@ def main():
         else:
             roof.update(bound='hbm', achieved=None, peak=PEAK_HBM_GBPS, unit='GB/s', frac=None)
         out = {
-            'metric': 'circuit-graphs/sec (train step), AIG-64k batch=64 per GPU', 'value': world * B * a.steps / elapsed,
+            'metric': 'circuit-graphs/sec (train step), AIG-64k batch=64 per GPU' if (a.config in (2, 4) and B == 64) else
+                      'circuit-graphs/sec (train step), config %d, %s, batch=%d per GPU' % (a.config, ctype, B),
+            'value': world * B * a.steps / elapsed,
             'unit': 'graphs/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': elapsed / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 (dense products as bf16x3 split-precision MFMA, fp32 accumulate)' if ops.PRECISION == 'x3' else 'f32', 'data': 'synthetic',
