@@ -278,8 +278,10 @@ template <int H>
 __global__ __launch_bounds__(kThreads) void k_func_bwd(int64_t P, const float* hf, const int64_t* pa, const int64_t* pb,
                                                        const float* tt, const float* dis, float eps, const double* ws,
                                                        const float* gscale, float* dhf) {
-    constexpr int LPR = H / 4, PPB = kThreads / LPR;
-    const int lr = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+    // one pair per H-lane group, one float per lane: every atomic wave-instruction adds whole contiguous rows (the shape
+    // the memory-side atomic units take at full rate; a float4-per-lane layout issues four strided adds per row)
+    constexpr int PPB = kThreads / H;
+    const int l = threadIdx.x % H, slot = threadIdx.x / H;
     const ZStats z = zstats(ws, P);
     const float g = *gscale;
     const float mean_s = (float)(ws[5] / (double)P), ssz = (float)(ws[6] / ((double)P - 1.0));
@@ -287,12 +289,12 @@ __global__ __launch_bounds__(kThreads) void k_func_bwd(int64_t P, const float* h
     for (int64_t p0 = (int64_t)blockIdx.x * PPB; p0 < P; p0 += (int64_t)gridDim.x * PPB) {
         const int64_t p = p0 + slot;
         const bool ok = p < P;
-        float4 x = zero4(), y = zero4();
+        float x = 0.f, y = 0.f;
         int64_t ia = 0, ib = 0;
-        if (ok) { ia = pa[p]; ib = pb[p]; x = ld4(hf + ia * H + 4 * lr); y = ld4(hf + ib * H + 4 * lr); }
-        const float xy = group_sum<LPR>(dot4(x, y));
-        const float xx = group_sum<LPR>(dot4(x, x));
-        const float yy = group_sum<LPR>(dot4(y, y));
+        if (ok) { ia = pa[p]; ib = pb[p]; x = hf[ia * H + l]; y = hf[ib * H + l]; }
+        const float xy = group_sum<H>(x * y);
+        const float xx = group_sum<H>(x * x);
+        const float yy = group_sum<H>(y * y);
         if (!ok) continue;
         const float zd = (dis[p] - z.mu_d) * z.inv_sd, zt = (tt[p] - z.mu_t) * z.inv_st;
         const float diff = zd - zt;
@@ -305,10 +307,8 @@ __global__ __launch_bounds__(kThreads) void k_func_bwd(int64_t P, const float* h
         const float cs = xy * inv;
         // cos = <x,y>/(nx ny); the norm factor only depends on x where it is not clamped
         const float kx = rx > eps ? cs / (nx * nx) : 0.f, ky = ry > eps ? cs / (ny * ny) : 0.f;
-        const float4 gx = make_float4(dc * (y.x * inv - kx * x.x), dc * (y.y * inv - kx * x.y), dc * (y.z * inv - kx * x.z), dc * (y.w * inv - kx * x.w));
-        const float4 gy = make_float4(dc * (x.x * inv - ky * y.x), dc * (x.y * inv - ky * y.y), dc * (x.z * inv - ky * y.z), dc * (x.w * inv - ky * y.w));
-        atomic_add4(dhf + ia * H + 4 * lr, gx);
-        atomic_add4(dhf + ib * H + 4 * lr, gy);
+        atomicAdd(dhf + ia * H + l, dc * (y * inv - kx * x));
+        atomicAdd(dhf + ib * H + l, dc * (x * inv - ky * y));
     }
 }
 
@@ -475,8 +475,12 @@ extern "C" int mgv_func_loss_bwd(int H, int64_t P, const float* hf, const int64_
                                  float* dhf, void* stream) {
     MGV_CHECK_ARG(P >= 2 && hf && pair_a && pair_b && tt && dis && ws && gscale && dhf);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_func_bwd<HH>), dim3(mgv::items_grid(P, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st,
-                                         P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, dhf));
+    switch (H) {     // one float per lane: the row must fit a wave
+        case 16: hipLaunchKernelGGL((mgv::k_func_bwd<16>), dim3(mgv::items_grid(P, mgv::kThreads / 16)), dim3(mgv::kThreads), 0, st, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, dhf); break;
+        case 32: hipLaunchKernelGGL((mgv::k_func_bwd<32>), dim3(mgv::items_grid(P, mgv::kThreads / 32)), dim3(mgv::kThreads), 0, st, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, dhf); break;
+        case 64: hipLaunchKernelGGL((mgv::k_func_bwd<64>), dim3(mgv::items_grid(P, mgv::kThreads / 64)), dim3(mgv::kThreads), 0, st, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, dhf); break;
+        default: return MGV_EUNSUPPORTED;
+    }
     MGV_LAUNCH_RET();
 }
 
