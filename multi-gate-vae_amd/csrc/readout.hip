@@ -77,18 +77,31 @@ __global__ __launch_bounds__(kThreads) void k_bn_act_bwd(int64_t N, int C, const
     if (r0 < rows) {
         const float4 m = ld4(mean + c4), is = ld4(invstd + c4), g = ld4(gamma + c4), b = ld4(beta + c4);
         const float mm[4] = {m.x, m.y, m.z, m.w}, ii[4] = {is.x, is.y, is.z, is.w}, gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
-        for (int64_t i = (int64_t)blockIdx.x * rows + r0; i < N; i += (int64_t)gridDim.x * rows) {
-            const float4 y = ld4(Y + i * C + c4), da = ld4(dA + i * C + c4);
-            const float yy[4] = {y.x, y.y, y.z, y.w}, dd[4] = {da.x, da.y, da.z, da.w};
-            float o[4];
+        const int64_t stride = (int64_t)gridDim.x * rows;
+        constexpr int U = 4;             // rows in flight per thread; their sums meet in fp32, then join the double totals
+        for (int64_t i0 = (int64_t)blockIdx.x * rows + r0; i0 < N; i0 += U * stride) {
+            float4 y[U], da[U];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float xhat = (yy[k] - mm[k]) * ii[k];
-                const float bn = xhat * gg[k] + bb[k];
-                const float dz = bn > 0.f ? dd[k] * drop_scale(seed, i * C + c4 + k, p, ks) : 0.f;
-                o[k] = dz; s[k] += dz; s2[k] += (double)dz * xhat;
-            }
-            st4(dZ + i * C + c4, make_float4(o[0], o[1], o[2], o[3]));
+            for (int u = 0; u < U; ++u)
+                if (i0 + u * stride < N) { y[u] = ld4(Y + (i0 + u * stride) * C + c4); da[u] = ld4(dA + (i0 + u * stride) * C + c4); }
+            float fs[4] = {0.f, 0.f, 0.f, 0.f}, fs2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (i0 + u * stride < N) {
+                    const int64_t i = i0 + u * stride;
+                    const float yy[4] = {y[u].x, y[u].y, y[u].z, y[u].w}, dd[4] = {da[u].x, da[u].y, da[u].z, da[u].w};
+                    float o[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float xhat = (yy[k] - mm[k]) * ii[k];
+                        const float bn = xhat * gg[k] + bb[k];
+                        const float dz = bn > 0.f ? dd[k] * drop_scale(seed, i * C + c4 + k, p, ks) : 0.f;
+                        o[k] = dz; fs[k] += dz; fs2[k] += dz * xhat;
+                    }
+                    st4(dZ + i * C + c4, make_float4(o[0], o[1], o[2], o[3]));
+                }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k] += fs[k]; s2[k] += fs2[k]; }
         }
     }
 #pragma unroll
@@ -111,21 +124,35 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(int64_t N, int C, con
     const int cq = C / 4;
     const int64_t total = N * cq;
     const double invn = 1.0 / (double)N;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
-        const int c4 = (int)(i % cq) * 4;
-        const float4 y = ld4(Y + i * 4), dz = ld4(dZ + i * 4);
-        const float yy[4] = {y.x, y.y, y.z, y.w}, zz[4] = {dz.x, dz.y, dz.z, dz.w};
-        float o[4];
+    // kThreads % cq == 0: a thread keeps its column quad over the grid-stride loop, so the per-column constants are
+    // formed once (they were re-read and re-multiplied in double per element)
+    const int c4 = (int)(threadIdx.x % cq) * 4;
+    float mm[4], sc[4], a1[4], a2[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int c = c4 + k;
-            const float is = invstd[c];
-            const float xhat = (yy[k] - mean[c]) * is;
-            float v = zz[k];
-            if (batch_stats) v -= (float)(sums[c] * invn) + xhat * (float)(sums[C + c] * invn);
-            o[k] = gamma[c] * is * v;
-        }
-        st4(dY + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+    for (int k = 0; k < 4; ++k) {
+        const int c = c4 + k;
+        const float is = invstd[c];
+        mm[k] = mean[c];
+        sc[k] = gamma[c] * is;
+        a1[k] = batch_stats ? (float)(sums[c] * invn) : 0.f;
+        a2[k] = batch_stats ? (float)(sums[C + c] * invn) * is : 0.f;       // multiplies (y - mean)
+    }
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    constexpr int U = 4;
+    for (int64_t i0 = (int64_t)blockIdx.x * kThreads + threadIdx.x; i0 < total; i0 += U * stride) {
+        float4 y[U], dz[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * stride < total) { y[u] = ld4(Y + (i0 + u * stride) * 4); dz[u] = ld4(dZ + (i0 + u * stride) * 4); }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * stride < total) {
+                const float yy[4] = {y[u].x, y[u].y, y[u].z, y[u].w}, zz[4] = {dz[u].x, dz[u].y, dz[u].z, dz[u].w};
+                float o[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = sc[k] * (zz[k] - a1[k] - (yy[k] - mm[k]) * a2[k]);
+                st4(dY + (i0 + u * stride) * 4, make_float4(o[0], o[1], o[2], o[3]));
+            }
     }
 }
 
