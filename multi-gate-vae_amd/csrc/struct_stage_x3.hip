@@ -84,7 +84,12 @@ struct X3Smem {
     static constexpr int ACC_F = kMaxClsX3 * 3 * H + 3 * H + 3 * H + H + H;
     static constexpr int b_idx = b_acc + ACC_F * 4;
     static constexpr int b_xe = b_idx + IDX_BYTES;                 // xe_hi, xe_lo: [64][XLD] columns = deg, onehot(cls) x8, 1, 0...
-    static constexpr int bwd_bytes = b_xe + 2 * kTileRows * XLD * 2;
+    // hi planes of Wc and Whh, row-major [3H][H+8] bf16, resident for the whole kernel: the recompute reads them as plain
+    // fragments, the dgrad reads the SAME rows transposed; only the lo planes still stream from L2 (half the L1 traffic)
+    static constexpr int WLD = H + 8;
+    static constexpr int WPB = 3 * H * WLD * 2;
+    static constexpr int b_w = b_xe + 2 * kTileRows * XLD * 2;
+    static constexpr int bwd_bytes = b_w + 2 * WPB;
     static_assert(bwd_bytes <= 160 * 1024, "backward LDS budget");
 };
 
@@ -270,7 +275,7 @@ __device__ __forceinline__ void tile_rows(const StageX3Args& a, int64_t base, in
 
 // gate pre-activations of one tile from the split planes; weights streamed from L2
 template <int H>
-__device__ __forceinline__ void stage_gemm_x3(const __bf16* wpack, const __bf16* agg_hi, const __bf16* agg_lo,
+__device__ __forceinline__ void stage_gemm_x3(const __bf16* wpack, const __bf16* wc_hi, const __bf16* whh_hi, const __bf16* agg_hi, const __bf16* agg_lo,
                                               const __bf16* hin_hi, const __bf16* hin_lo,
                                               f32x4 (&ar)[SplitX3<H>::RTW][SplitX3<H>::HCW],
                                               f32x4 (&az)[SplitX3<H>::RTW][SplitX3<H>::HCW],
@@ -303,8 +308,9 @@ __device__ __forceinline__ void stage_gemm_x3(const __bf16* wpack, const __bf16*
             for (int g = 0; g < 3; ++g) {
                 // fragment order: block (row tile, k-step) = 512 contiguous elements, lane l at 8*l
                 const int wo = ((g * (H / 16) + wc * S::HCW + j) * (H / 32) + ks) * 512 + lane * 8;
-                const bf16x8 ch = ldfrag(wpack + 0 * BLK + wo), cl = ldfrag(wpack + 1 * BLK + wo);
-                const bf16x8 uh = ldfrag(wpack + 2 * BLK + wo), ul = ldfrag(wpack + 3 * BLK + wo);
+                const int lo = (g * H + col) * (H + 8) + ko;           // row-major hi planes in LDS
+                const bf16x8 ch = ldfrag(wc_hi + lo), cl = ldfrag(wpack + 1 * BLK + wo);
+                const bf16x8 uh = ldfrag(whh_hi + lo), ul = ldfrag(wpack + 3 * BLK + wo);
 #pragma unroll
                 for (int i = 0; i < S::RTW; ++i) {
                     if (g == 0) { mma_x3(ar[i][j], ah[i], al[i], ch, cl); mma_x3(ar[i][j], hh[i], hl[i], uh, ul); }
@@ -560,6 +566,17 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
     float* s_dy = reinterpret_cast<float*>(smem_raw + M::b_c + M::F32TILE);
     __bf16* d_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_c);                       // aliases s_pre/s_dy
     const SmallVecs sv = stage_small<H>(a, reinterpret_cast<float*>(smem_raw + M::b_small));
+    __bf16* wc_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_w);
+    __bf16* whh_hi = reinterpret_cast<__bf16*>(smem_raw + M::b_w + M::WPB);
+    {   // fragment-order hi blocks of the pack (0: Wc, 2: Whh) -> row-major LDS planes, 8 k-contiguous elements per copy
+        constexpr int KSN = H / 32;
+        for (int v = threadIdx.x; v < 3 * H * H / 8; v += kThreadsX3) {
+            const int blk = v >> 6, ln = v & 63;
+            const int row = (blk / KSN) * 16 + (ln & 15), k = (blk % KSN) * 32 + (ln >> 4) * 8;
+            *reinterpret_cast<bf16x8*>(wc_hi + row * M::WLD + k) = ldfrag(a.wpack + 0 * 3 * H * H + v * 8);
+            *reinterpret_cast<bf16x8*>(whh_hi + row * M::WLD + k) = ldfrag(a.wpack + 2 * 3 * H * H + v * 8);
+        }
+    }
     float* s_stat = reinterpret_cast<float*>(smem_raw + M::b_stat);
     float* s_dxt = reinterpret_cast<float*>(smem_raw + M::b_acc);
     float* s_dbc = s_dxt + kMaxClsX3 * 3 * H;
@@ -641,7 +658,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
         STAMP(1);
         // ---- B. recompute gates; keep the own-row values (hi+lo) for the GRU backward
         f32x4 ar[S::RTW][S::HCW], az[S::RTW][S::HCW], ani[S::RTW][S::HCW], anh[S::RTW][S::HCW];
-        stage_gemm_x3<H>(a.wpack, agg_hi, agg_lo, hin_hi, hin_lo, ar, az, ani, anh);
+        stage_gemm_x3<H>(a.wpack, wc_hi, whh_hi, agg_hi, agg_lo, hin_hi, hin_lo, ar, az, ani, anh);
         idx_prefetch<kThreadsX3>(a, idx_lds(idx_base, b ^ 1).ptr, ri);          // after the weight fragments (vmcnt is in order); committed at the tile's end
         rp = ptr_prefetch(a, tile + 2 * (int64_t)gridDim.x, ntiles);
         tile_dmax(idx_lds(idx_base, b ^ 1).ptr, idx_lds(idx_base, b ^ 1).dmax());
@@ -777,13 +794,14 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
 #pragma unroll
                         for (int j = 0; j < S::HCW; ++j) {
                             const int wo = (((wc * S::HCW + j) * 3 + g) * (H / 32) + ks) * 512 + lane * 8;   // fragment order
+                            const int jc = (wc * S::HCW + j) * 16;
                             if (p != 3) {
-                                const bf16x8 bh = ldfrag(a.wpack + 4 * BLK + wo), bl = ldfrag(a.wpack + 5 * BLK + wo);
+                                const bf16x8 bh = ldfrag_tr(wc_hi + g * H * M::WLD, M::WLD, 32 * ks, jc), bl = ldfrag(a.wpack + 5 * BLK + wo);
 #pragma unroll
                                 for (int i = 0; i < S::RTW; ++i) mma_x3(dag[i][j], xh[i], xl[i], bh, bl);
                             }
                             if (p != 2) {
-                                const bf16x8 bh = ldfrag(a.wpack + 6 * BLK + wo), bl = ldfrag(a.wpack + 7 * BLK + wo);
+                                const bf16x8 bh = ldfrag_tr(whh_hi + g * H * M::WLD, M::WLD, 32 * ks, jc), bl = ldfrag(a.wpack + 7 * BLK + wo);
 #pragma unroll
                                 for (int i = 0; i < S::RTW; ++i) mma_x3(dhd[i][j], xh[i], xl[i], bh, bl);
                             }
