@@ -32,9 +32,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, fp32-input matrix peak (
 PEAK_HBM_GBPS = 8000.0           # HBM3E spec (6.3 TB/s is what a streaming copy reaches)
 
 
-def cpu_baseline(cfg, H, rounds, seed_sd, graphs=4):
+def cpu_baseline(cfg, H, rounds, seed_sd, graphs=4, hip_losses=None):
     """Oracle train step (oracle/ref_cpu.py, O(edges) sweep) on `graphs` graphs of the workload — a
-    bounded sample — on the host cores this process may use (capped at the box's 16-core share)."""
+    bounded sample — on the host cores this process may use (capped at the box's 16-core share).
+    `hip_losses(arrays)`: the three losses of the HIP path on the same sample (seed weights, the sample's fixed
+    negatives, dropout off), compared with the oracle's in `loss_parity`."""
     from deepgate import synthetic as syn
     from oracle import ref_cpu as R
     cores = max(1, min(16, len(os.sched_getaffinity(0))))
@@ -61,9 +63,22 @@ def cpu_baseline(cfg, H, rounds, seed_sd, graphs=4):
     arrays = syn.make_batch(cfg, batch=graphs)
     dt = one_step(arrays)
     print('[cpu_baseline] %.1f s' % dt, file=sys.stderr, flush=True)
-    return {'value': graphs / dt, 'unit': 'graphs/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 train step on %d graphs of the workload (%d nodes), oracle/ref_cpu.py with the O(edges) sweep, %.1f s'
-                      % (graphs, arrays['num_nodes'], dt)}
+    out = {'value': graphs / dt, 'unit': 'graphs/s', 'cores': cores, 'kind': 'port',
+           'sample': '1 train step on %d graphs of the workload (%d nodes), oracle/ref_cpu.py with the O(edges) sweep, %.1f s'
+                     % (graphs, arrays['num_nodes'], dt)}
+    if hip_losses is not None:
+        print('[cpu_baseline] loss parity on the same sample (dropout off) ...', file=sys.stderr, flush=True)
+        ob = R.batch_from_arrays(lambda k: arrays[k])
+        p = {k: v.detach().cpu().clone() for k, v in seed_sd.items()}
+        bn = {k: v.clone() for k, v in p.items() if 'running_' in k}
+        with torch.no_grad():
+            ls = R.run_batch(p, ctype, ob, training=True, bn_state=bn, p_drop=0.0, s_rounds=rounds, t_rounds=rounds,
+                             plan=R.LevelPlan(ctype, ob['edge_index'], ob['gate'], ob['forward_level']), fast=True)
+        ref = [float(ls[k]) for k in ('recon_loss', 'prob_loss', 'func_loss')]
+        got = hip_losses(arrays)
+        out['loss_parity'] = {'oracle': ref, 'hip': got, 'abs_diff': [abs(a - b) for a, b in zip(got, ref)],
+                              'note': 'recon, prob, func on the cpu_baseline sample; target 1e-4 (north_star)'}
+    return out
 
 
 def main():
@@ -195,7 +210,20 @@ def main():
             'plan_ms': plan_ms, 'losses': losses, 'roofline': roof,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(a.config, H, rounds, seed_sd)
+            def hip_losses(sample):
+                enc2 = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=H, s_rounds=rounds, t_rounds=rounds, layernorm=True)
+                m2 = mod.Model(struct_encoder=enc2, dim_hidden=H, enable_encode=True, enable_reverse=True)
+                m2.load_state_dict(seed_sd)
+                for mm in m2.modules():
+                    if isinstance(mm, torch.nn.Dropout):
+                        mm.p = 0.0
+                t2 = deepgate.Trainer(targs, m2, training_id='parity', save_dir='/tmp/mgv_bench_parity', lr=1e-4,
+                                      rc_prob_func_weight=[1.0, 4.0, 4.0], device=str(dev), batch_size=1, distributed=False)
+                m2.train()
+                with torch.no_grad():
+                    l2 = t2.run_batch(deepgate.CircuitBatch.from_arrays(sample, device=dev))     # fixed negatives of the sample
+                return [float(l2[k]) for k in ('recon_loss', 'prob_loss', 'func_loss')]
+            out['cpu_baseline'] = cpu_baseline(a.config, H, rounds, seed_sd, hip_losses=hip_losses)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
