@@ -1,0 +1,97 @@
+"""GPU cross-checks of the struct-stage code paths on a graph with hub nodes (fan-out 3000, fan-in 1500): the neighbour
+index list of a hub's tile does not fit the LDS staging buffer, so the kernels take their generic per-row path there
+while the other tiles take the chunked one.  Compared: bf16x3 kernels vs exact-fp32 kernels (independent code), and the
+(degree, class)-table first half round vs the per-node launch (which must agree to rounding: same kernel arithmetic)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _hub_graph(rng, n=6000):
+    src, dst = [], []
+    for v in range(64, n):                                  # a random DAG by node order
+        for p in rng.choice(v, size=int(rng.integers(1, 4)), replace=False):
+            src.append(int(p)); dst.append(v)
+    for v in rng.choice(np.arange(64, n), size=3000, replace=False):     # fan-out hub: node 3
+        src.append(3); dst.append(int(v))
+    for p in rng.choice(np.arange(0, n - 1), size=1500, replace=False):  # fan-in hub: the last node
+        src.append(int(p)); dst.append(n - 1)
+    return np.unique(np.array([src, dst], dtype=np.int64), axis=1), n
+
+
+def _run(dev, ei, n, precision, first_stage):
+    import deepgate
+    from deepgate import ops
+    old = (ops.PRECISION, ops.FIRST_STAGE_TABLE)
+    ops.PRECISION, ops.FIRST_STAGE_TABLE = precision, first_stage == 'table'
+    try:
+        torch.manual_seed(11)
+        enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=64, s_rounds=2, t_rounds=2, layernorm=True).to(dev)
+        rng = np.random.default_rng(2)
+        x = torch.zeros(n, 6, device=dev)
+        x[torch.arange(n), torch.from_numpy(rng.integers(0, 6, n)).to(dev)] = 1.0
+        s, t = enc(x, x, torch.from_numpy(ei).to(dev))
+        gs, gt = torch.randn(n, 64, device=dev, generator=torch.Generator(dev).manual_seed(5)), torch.randn(n, 64, device=dev, generator=torch.Generator(dev).manual_seed(6))
+        ((s * gs).sum() + (t * gt).sum()).backward()
+        return [s.detach(), t.detach()] + [p.grad.detach().clone() for p in enc.parameters()], [k for k, _ in enc.named_parameters()]
+    finally:
+        ops.PRECISION, ops.FIRST_STAGE_TABLE = old
+
+
+def _truth(ei, n):
+    """float64 torch restatement of the two encoders (digae_layer.py:257-277) on the CPU, same seeds as _run."""
+    import deepgate
+    import torch.nn.functional as F
+    torch.manual_seed(11)
+    enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=64, s_rounds=2, t_rounds=2, layernorm=True).double()
+    rng = np.random.default_rng(2)
+    x = torch.zeros(n, 6, dtype=torch.float64)
+    x[torch.arange(n), torch.from_numpy(rng.integers(0, 6, n))] = 1.0
+    src, dst = torch.from_numpy(ei[0]), torch.from_numpy(ei[1])
+    outs = []
+    for conv in (enc.source_conv, enc.target_conv):
+        h = torch.ones(n, 64, dtype=torch.float64)
+        for _ in range(2):
+            for ag, gru, a, b in ((conv.aggr, conv.update, src, dst), (conv.aggr_r, conv.update_r, dst, src)):
+                m = torch.zeros(n, 64, dtype=torch.float64).index_add_(0, b, h[a] @ ag.msg.weight.t() + ag.msg.bias)
+                gi = torch.cat([m, x], 1) @ gru.weight_ih_l0.t() + gru.bias_ih_l0
+                gh = h @ gru.weight_hh_l0.t() + gru.bias_hh_l0
+                (ir, iz, inn), (hr, hz, hn) = gi.chunk(3, 1), gh.chunk(3, 1)
+                r, z = torch.sigmoid(ir + hr), torch.sigmoid(iz + hz)
+                h = F.layer_norm((1 - z) * torch.tanh(inn + r * hn) + z * h, (64,), conv.ln.weight, conv.ln.bias)
+        outs.append(h)
+    dev = torch.device('cuda:0')
+    gs = torch.randn(n, 64, device=dev, generator=torch.Generator(dev).manual_seed(5)).cpu().double()
+    gt = torch.randn(n, 64, device=dev, generator=torch.Generator(dev).manual_seed(6)).cpu().double()
+    ((outs[0] * gs).sum() + (outs[1] * gt).sum()).backward()
+    return [outs[0].detach(), outs[1].detach()] + [p.grad.clone() for p in enc.parameters()]
+
+
+def test_struct_paths_agree_on_a_hub_graph():
+    dev = _dev()
+    ei, n = _hub_graph(np.random.default_rng(0))
+    truth = _truth(ei, n)
+    runs = {}
+    for precision in ('f32', 'x3'):
+        for first in ('full', 'table'):
+            runs[precision, first], names = _run(dev, ei, n, precision, first)
+    names = ['s', 't'] + names
+
+    def worst(a_list, b_list):
+        return max((float((a.cpu().double() - b.cpu().double()).abs().max()) / float(b.abs().max()), nm)
+                   for nm, a, b in zip(names, a_list, b_list) if float(b.abs().max()) > 1e-6)
+    # against float64: the hubs sum 1500-3000 rows, which conditions the gradients badly; measured 5e-4 (fp32 kernels) and
+    # 3e-3 (bf16x3), against 3e-5 for bf16x3 on the same graph without the hub edges
+    assert worst(runs['f32', 'full'], truth)[0] <= 2e-3, worst(runs['f32', 'full'], truth)
+    assert worst(runs['x3', 'full'], truth)[0] <= 1e-2, worst(runs['x3', 'full'], truth)
+    # the (degree, class)-table first half round is the same arithmetic as the per-node launch
+    for precision, tol in (('f32', 2e-4), ('x3', 2e-3)):
+        assert worst(runs[precision, 'table'], runs[precision, 'full'])[0] <= tol, (precision, worst(runs[precision, 'table'], runs[precision, 'full']))

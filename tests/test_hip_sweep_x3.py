@@ -1,0 +1,82 @@
+"""GPU checks of the bf16x3 level-sweep kernels (csrc/func_level_x3.hip) against the exact-fp32 sweep kernels
+(csrc/func_level.hip, themselves checked against the reference fixtures in test_hip_model.py) on graphs built to hit
+the paths the BASELINE shapes do not: fan-in beyond the gathered-together rows (kInRegs = 3) and beyond the staged
+in-edge list (kInCap = 4), fan-out beyond the staged out-edge list (kOutCap = 16), partial tiles, five gate types,
+nodes no aggregator updates.  Tolerance: 2e-4 of the largest entry (bf16x3 products, fp32 everything else)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _graph(rng, n_in, levels, per, T, hub_fanout, big_fanin):
+    """Levelised DAG: node k of a level takes its first parent from the previous level, the rest from anywhere
+    earlier; node 0 (an input) additionally feeds `hub_fanout` nodes, one node per level has `big_fanin` parents."""
+    n = n_in + levels * per
+    src, dst = [], []
+    gate = np.zeros(n, dtype=np.int64)
+    level = np.zeros(n, dtype=np.int64)
+    for lv in range(1, levels + 1):
+        lo = n_in + (lv - 1) * per
+        prev_lo = 0 if lv == 1 else n_in + (lv - 2) * per
+        prev_hi = lo
+        for k in range(per):
+            v = lo + k
+            level[v] = lv
+            gate[v] = 1 + (k % T) if k % 7 != 6 else 9             # gate id 9: not updated by any aggregator
+            fanin = big_fanin if k == 1 else int(rng.integers(1, 4))
+            ps = {int(rng.integers(prev_lo, prev_hi))}
+            while len(ps) < min(fanin, lo):
+                ps.add(int(rng.integers(0, lo)))
+            for p in ps:
+                src.append(p); dst.append(v)
+    hubs = rng.choice(np.arange(n_in, n), size=hub_fanout, replace=False)
+    for v in hubs:
+        if not any(s == 0 and d == v for s, d in zip(src[-200:], dst[-200:])):
+            src.append(0); dst.append(int(v))
+    ei = np.unique(np.array([src, dst], dtype=np.int64), axis=1)
+    return ei, gate, level, n
+
+
+@pytest.mark.parametrize('H,T', [(64, 5), (32, 2)])
+def test_sweep_x3_matches_fp32_sweep_on_irregular_graphs(H, T):
+    dev = _dev()
+    from deepgate import ops
+    from deepgate.graph_plan import GraphPlan
+    if ops.PRECISION != 'x3':
+        pytest.skip('bf16x3 mode only')
+    rng = np.random.default_rng(5 + H)
+    ei, gate, level, n = _graph(rng, n_in=40, levels=9, per=75, T=T, hub_fanout=60, big_fanin=7)   # 75 nodes/level: partial tiles
+    plan = GraphPlan(torch.from_numpy(ei).to(dev), n)
+    plan.set_levels(torch.from_numpy(gate).to(dev), torch.from_numpy(level).to(dev), list(range(1, T + 1)))
+    assert int((plan.out_ptr[1:] - plan.out_ptr[:-1]).max()) > 16 and int((plan.in_ptr[1:] - plan.in_ptr[:-1]).max()) > 4
+    torch.manual_seed(H)
+    hs0 = torch.randn(n, H, device=dev)
+    par0 = [torch.randn(T, 2 * H, device=dev) * 0.3, torch.randn(T, 3 * H, 2 * H, device=dev) * 0.15,
+            torch.randn(T, 3 * H, device=dev) * 0.1, torch.randn(T, 3 * H, device=dev) * 0.1, torch.randn(T, 3 * H, device=dev) * 0.1]
+    ghf = torch.randn(n, H, device=dev)
+    results = []
+    import os
+    for x3 in ('1', '0'):
+        os.environ['MGV_SWEEP_X3'] = x3
+        hs = hs0.clone().requires_grad_(True)
+        par = [p.clone().requires_grad_(True) for p in par0]
+        hf = ops.FuncSweepFn.apply(plan, hs, *par)
+        (hf * ghf).sum().backward()
+        results.append([hf.detach()] + [hs.grad] + [p.grad for p in par])
+    os.environ.pop('MGV_SWEEP_X3', None)
+    names = ['hf', 'd hs', 'd attn_u', 'd Wvc', 'd bvc', 'd bih', 'd bhh']
+    for name, a, b in zip(names, *results):
+        scale = float(b.abs().max())
+        assert scale > 0, name
+        assert float((a - b).abs().max()) <= 2e-4 * scale, (name, float((a - b).abs().max()), scale)
+    # nodes of the unknown gate type and the inputs keep hf = 0
+    idle = torch.from_numpy((gate == 9) | (level == 0)).to(dev)
+    assert float(results[0][0][idle].abs().max()) == 0.0
