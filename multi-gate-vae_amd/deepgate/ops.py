@@ -6,7 +6,7 @@ streams and the autograd tape; all arithmetic on [N,*] data happens in libmgvae_
 import torch
 
 from . import _hip
-from ._hip import check, ptr
+from ._hip import HipLibraryError, check, ptr
 
 import os
 
