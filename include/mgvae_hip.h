@@ -69,6 +69,19 @@ int mgv_struct_stage_bwd_x3(int H, int64_t N, const float* h_in, const int32_t* 
                             float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
                             float* dln_b, void* stream);
 
+/* Second decomposition of the bf16x3 backward (H = 64 only): all weight fragments register-resident, transposed
+ * products, one dgrad+wgrad phase per tile, and NO float atomics: parameter gradients leave through per-workgroup
+ * slabs in `workspace` (mgv_struct_stage_bwd2_ws_floats(H, N) floats, device memory, contents irrelevant before and
+ * after) and a fixed-order reduction, so two identical calls give bit-identical gradients.  Same reference lines and
+ * argument meaning as mgv_struct_stage_bwd_x3 (digae_layer.py:266-275 under autograd). */
+int mgv_struct_stage_bwd2_ws_floats(int H, int64_t N);   /* a size, not a status */
+int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
+                             const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
+                             const float* bhh, const float* ln_w, const float* ln_b, float ln_eps,
+                             const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
+                             float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
+                             float* dln_b, float* workspace, int64_t workspace_floats, void* stream);
+
 /* ---- Linear over node rows (hs_linear dg_ae_model_aig.py:64, hs_decompose :109, fc_{s,t}_{mu,logstd}
  * digvae_model.py:135-136, readout Linear layers mlp.py:29,38; also the dgrad with W^T):
  *   Y[N][M] = [X1 | X2] W^T + b     (X2/K2 = NULL/0 unless a torch.cat of two inputs is fused, :64)

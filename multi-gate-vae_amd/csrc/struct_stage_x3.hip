@@ -6,272 +6,9 @@
 // Weights arrive pre-split by the host in one bf16 pack of eight [3H*H] blocks:
 //   0 Wc_hi  1 Wc_lo  2 Whh_hi  3 Whh_lo   ([3H][H], k contiguous: forward B operands)
 //   4 WcT_hi 5 WcT_lo 6 WhhT_hi 7 WhhT_lo  ([H][3H], k contiguous: dgrad B operands)
-#include "mgv_x3.h"
-#include "../../include/mgvae_hip.h"
+#include "struct_stage_x3_common.h"
 
 namespace mgv {
-
-struct StageX3Args {
-    unsigned long long* stamps;   // diagnostic build only (MGV_STAMPS): [8 waves][16 phases] cycle sums
-    int64_t N;
-    const float* h_in;
-    const int32_t* ptr;
-    const int32_t* idx;
-    const uint8_t* xcls;
-    const float* xtab;
-    int C;
-    const __bf16* wpack;
-    const float* bc;
-    const float* bhh;
-    const float* lnw;
-    const float* lnb;
-    float eps;
-    float* h_out;
-    const float* gy_direct;
-    const float* gy_agg;
-    float* g_direct_out;
-    float* g_agg_out;
-    float* dWc; float* dbc; float* dWhh; float* dbhh; float* dxtab; float* dlnw; float* dlnb;
-};
-
-#include "mgv_stamps.h"
-
-constexpr int kMaxClsX3 = 8;
-constexpr int kTPR = 2;                 // gate-gradient tiles staged in LDS per round of the backward phase E (4 spills registers: 7.4 vs 4.6 ms)
-constexpr int XLD = 24;                 // row-major [64][16 (+8 pad)] planes of [deg, onehot(cls) x8, 1, 0..]
-constexpr int kNW = 8;                  // waves per workgroup (two per SIMD)
-constexpr int kThreadsX3 = kNW * 64;
-constexpr int kIdxCap = 1024;           // neighbour entries of one tile kept in LDS; the tail is read from global
-constexpr int kPtrPad = 80;             // 65 CSR pointers of a tile + the tile's maximum degree at [72], padded
-
-// 8 waves over a (64 rows) x (H hidden columns) output: across column tiles first, then row tiles
-template <int H>
-struct SplitX3 {
-    static constexpr int HC = H / 16;
-    static constexpr int WPC = HC < 4 ? HC : 4;
-    static constexpr int WPR = kNW / WPC;
-    static constexpr int RTW = 4 / WPR;
-    static_assert(RTW >= 1, "too many waves for the tile");
-    static constexpr int HCW = HC / WPC;
-    static constexpr int LD = H + 4;
-    static constexpr int LPR = H / 4;
-    static constexpr int GROUPS = kThreadsX3 / LPR;
-};
-
-template <int H>
-struct X3Smem {
-    using S = SplitX3<H>;
-    static constexpr int LDP = H + 8;                         // bf16 elements per row-major plane row
-    static constexpr int PB = kTileRows * LDP * 2;            // bytes of a row-major plane
-    static constexpr int F32TILE = kTileRows * S::LD * 4;
-    static constexpr int SMALL_F = kMaxClsX3 * 3 * H + 3 * H + 3 * H + H + H + kTileRows + kTileRows;   // floats
-    // forward
-    static constexpr int f_planes = 0;                        // agg_hi, agg_lo, hin_hi, hin_lo
-    static constexpr int f_hin = f_planes + 4 * PB;           // fp32 own rows
-    static constexpr int f_pre = f_planes;                    // fp32 pre-LayerNorm rows: reuse the agg planes once the MFMAs are done
-    static_assert(F32TILE <= 2 * PB, "pre-LN tile must fit the two agg planes");
-    static constexpr int f_small = f_hin + F32TILE;
-    static constexpr int IDX_BYTES = 2 * (kPtrPad + kIdxCap + 8) * 4;
-    static constexpr int f_idx = f_small + SMALL_F * 4;
-    static constexpr int fwd_bytes = f_idx + IDX_BYTES;
-    // backward
-    static constexpr int b_planes = 0;                        // region A: row-major operand planes
-    static constexpr int b_c = b_planes + 4 * PB;             // region C: {pre, dy fp32} then {d_hi, d_lo}
-    static constexpr int C_BYTES = (2 * F32TILE > 2 * kTPR * PB) ? 2 * F32TILE : 2 * kTPR * PB;   // kTPR gate-gradient tiles (hi, lo each) per round
-    static constexpr int b_small = b_c + C_BYTES;
-    static constexpr int b_stat = b_small + SMALL_F * 4;      // 4 floats per row
-    static constexpr int b_acc = b_stat + 4 * kTileRows * 4;  // dxt[C*3H], dbc[3H], dbhh[3H], dlnw[H], dlnb[H]
-    static constexpr int ACC_F = kMaxClsX3 * 3 * H + 3 * H + 3 * H + H + H;
-    static constexpr int b_idx = b_acc + ACC_F * 4;
-    static constexpr int b_xe = b_idx + IDX_BYTES;                 // xe_hi, xe_lo: [64][XLD] columns = deg, onehot(cls) x8, 1, 0...
-    // hi planes of Wc and Whh, row-major [3H][H+8] bf16, resident for the whole kernel: the recompute reads them as plain
-    // fragments, the dgrad reads the SAME rows transposed; only the lo planes still stream from L2 (half the L1 traffic)
-    static constexpr int WLD = H + 8;
-    static constexpr int WPB = 3 * H * WLD * 2;
-    static constexpr int b_w = b_xe + 2 * kTileRows * XLD * 2;
-    static constexpr int bwd_bytes = b_w + 2 * WPB;
-    static_assert(bwd_bytes <= 160 * 1024, "backward LDS budget");
-};
-
-struct SmallVecs {
-    const float* xtab; const float* bc; const float* bhh; const float* lnw; const float* lnb; float* deg; int* cls;
-};
-
-template <int H>
-__device__ __forceinline__ SmallVecs stage_small(const StageX3Args& a, float* base) {
-    SmallVecs v;
-    float* xtab = base;
-    float* bc = xtab + kMaxClsX3 * 3 * H;
-    float* bhh = bc + 3 * H;
-    float* lnw = bhh + 3 * H;
-    float* lnb = lnw + H;
-    float* deg = lnb + H;
-    int* cls = reinterpret_cast<int*>(deg + kTileRows);
-    const int tid = threadIdx.x;
-    const int nt = blockDim.x;
-    for (int i = tid; i < a.C * 3 * H; i += nt) xtab[i] = a.xtab[i];
-    for (int i = tid; i < 3 * H; i += nt) { bc[i] = a.bc[i]; bhh[i] = a.bhh[i]; }
-    for (int i = tid; i < H; i += nt) { lnw[i] = a.lnw ? a.lnw[i] : 1.0f; lnb[i] = a.lnb ? a.lnb[i] : 0.0f; }
-    v.xtab = xtab; v.bc = bc; v.bhh = bhh; v.lnw = lnw; v.lnb = lnb; v.deg = deg; v.cls = cls;
-    return v;
-}
-
-
-// ---- neighbour-index prefetch.  The row gathers are the only HBM-latency-bound part of the kernel, so
-// the CSR pointers and indices of tile t+1 are fetched while tile t is being computed and parked in LDS;
-// the row phase of a tile then consists of independent loads only (own rows + up to 4 neighbour rows
-// per lane group in flight at once).
-// one of two LDS buffers, addressed by arithmetic on the shared-memory base (a dynamically indexed array of pointer
-// structs would hide the address space from the compiler and turn every index read into a flat_load)
-constexpr int kIdxStride = kPtrPad + kIdxCap + 8;
-struct IdxLds { int* ptr; int* idx; __device__ int* dmax() const { return ptr + 72; } };
-__device__ __forceinline__ IdxLds idx_lds(int* idx_base, int b) { return IdxLds{idx_base + b * kIdxStride, idx_base + b * kIdxStride + kPtrPad}; }
-
-__device__ __forceinline__ int ptr_prefetch(const StageX3Args& a, int64_t tile, int64_t ntiles) {
-    if (tile >= ntiles || threadIdx.x > kTileRows) return 0;
-    int64_t n = tile * kTileRows + threadIdx.x;
-    n = n < a.N ? n : a.N;
-    return a.ptr[n];
-}
-
-template <int NT>
-__device__ __forceinline__ void idx_prefetch(const StageX3Args& a, const int* s_ptr, int (&ri)[kIdxCap / NT]) {
-    const int e0 = s_ptr[0], ne = s_ptr[kTileRows] - e0;
-#pragma unroll
-    for (int k = 0; k < kIdxCap / NT; ++k) {
-        const int i = threadIdx.x + k * NT;
-        ri[k] = i < ne ? a.idx[e0 + i] : 0;
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void idx_commit(int* s_idx, const int (&ri)[kIdxCap / NT]) {
-#pragma unroll
-    for (int k = 0; k < kIdxCap / NT; ++k) s_idx[threadIdx.x + k * NT] = ri[k];
-}
-
-// maximum neighbour count of a tile's rows, from the CSR pointers parked in LDS (executed by wave 0)
-__device__ __forceinline__ void tile_dmax(const int* s_ptr, int* s_dmax) {
-    if (threadIdx.x < 64) {
-        int d = s_ptr[threadIdx.x + 1] - s_ptr[threadIdx.x];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) d = max(d, __shfl_xor(d, m, 64));
-        const int ne = s_ptr[kTileRows] - s_ptr[0];
-        if (threadIdx.x == 0) *s_dmax = ne > kIdxCap - 8 ? (1 << 30) : d;    // index list does not fit LDS: generic path
-    }
-}
-
-// Row loads of RPG tile rows per lane group: own rows first, then the neighbour lists in chunks of D
-// slots per row.  Within a chunk every index is read from LDS unconditionally and every row load is
-// only predicated (no waits, no dummy traffic), so RPG*D row loads (x2 with DY) are in flight per lane.
-// The chunk loop's trip count is the tile's maximum degree: workgroup-uniform.
-template <int H, int D, int RPG, bool DY>
-__device__ __forceinline__ void rows_chunked(const StageX3Args& a, int64_t base, int grp, int groups, int lr, const int* s_ptr,
-                                             const int* s_idx, int dmax, bool two, float4 (&acc)[RPG], float4 (&own)[RPG],
-                                             float4 (&dy)[RPG], float (&deg)[RPG], int (&cls)[RPG]) {
-    // caller guarantees: the whole tile lies inside [0, N) and its index list inside LDS
-    const int e0t = s_ptr[0];
-    int rel0[RPG], d[RPG];
-#pragma unroll
-    for (int rr = 0; rr < RPG; ++rr) {
-        const int row = grp + rr * groups;
-        const int p0 = s_ptr[row];
-        rel0[rr] = p0 - e0t;
-        d[rr] = s_ptr[row + 1] - p0;
-    }
-    // chunk 0 is peeled so that its row loads are issued together with the own-row loads
-    int j0[RPG][D];
-#pragma unroll
-    for (int rr = 0; rr < RPG; ++rr)
-#pragma unroll
-        for (int k = 0; k < D; ++k) j0[rr][k] = s_idx[min(rel0[rr] + k, kIdxCap + 7)];
-    f32x4 v0[RPG][D], g0[RPG][D];
-#pragma unroll
-    for (int rr = 0; rr < RPG; ++rr) {
-        const int64_t node = base + grp + rr * groups;
-        own[rr] = ld4(a.h_in + node * H + 4 * lr);
-        if (DY) dy[rr] = ld4(a.gy_direct + node * H + 4 * lr); else dy[rr] = zero4();
-        cls[rr] = a.xcls[node];
-        // predicated loads into registers that are NOT written on the untaken path (a zero-initialised
-        // destination would be a write-after-write hazard and make the compiler drain vmcnt per load)
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            if (k < d[rr]) {
-                v0[rr][k] = *reinterpret_cast<const f32x4*>(a.h_in + (int64_t)j0[rr][k] * H + 4 * lr);
-                if (DY && two) g0[rr][k] = *reinterpret_cast<const f32x4*>(a.gy_agg + (int64_t)j0[rr][k] * H + 4 * lr);
-            }
-    }
-#pragma unroll
-    for (int rr = 0; rr < RPG; ++rr) {
-        deg[rr] = (float)d[rr];
-        acc[rr] = zero4();
-#pragma unroll
-        for (int k = 0; k < D; ++k)
-            if (k < d[rr]) {
-                acc[rr] = add4(acc[rr], make_float4(v0[rr][k][0], v0[rr][k][1], v0[rr][k][2], v0[rr][k][3]));
-                if (DY && two) dy[rr] = add4(dy[rr], make_float4(g0[rr][k][0], g0[rr][k][1], g0[rr][k][2], g0[rr][k][3]));
-            }
-    }
-    for (int c0 = D; c0 < dmax; c0 += D) {
-        int j[RPG][D];
-#pragma unroll
-        for (int rr = 0; rr < RPG; ++rr)
-#pragma unroll
-            for (int k = 0; k < D; ++k) j[rr][k] = s_idx[min(rel0[rr] + c0 + k, kIdxCap + 7)];
-        f32x4 v[RPG][D], g[RPG][D];
-#pragma unroll
-        for (int rr = 0; rr < RPG; ++rr)
-#pragma unroll
-            for (int k = 0; k < D; ++k)
-                if (c0 + k < d[rr]) {
-                    v[rr][k] = *reinterpret_cast<const f32x4*>(a.h_in + (int64_t)j[rr][k] * H + 4 * lr);
-                    if (DY && two) g[rr][k] = *reinterpret_cast<const f32x4*>(a.gy_agg + (int64_t)j[rr][k] * H + 4 * lr);
-                }
-#pragma unroll
-        for (int rr = 0; rr < RPG; ++rr)
-#pragma unroll
-            for (int k = 0; k < D; ++k)
-                if (c0 + k < d[rr]) {
-                    acc[rr] = add4(acc[rr], make_float4(v[rr][k][0], v[rr][k][1], v[rr][k][2], v[rr][k][3]));
-                    if (DY && two) dy[rr] = add4(dy[rr], make_float4(g[rr][k][0], g[rr][k][1], g[rr][k][2], g[rr][k][3]));
-                }
-    }
-}
-
-// generic degree: per-row loops (rare tiles with a high fan-out node or an index list beyond LDS)
-template <int H, bool DY>
-__device__ __forceinline__ void row_generic(const StageX3Args& a, int64_t node, int row, int lr, const int* s_ptr, bool two,
-                                            float4& acc, float4& own, float4& dy, float& deg, int& cls) {
-    acc = zero4(); own = zero4(); dy = zero4(); deg = 0.f; cls = 0;
-    if (node >= a.N) return;
-    const int p0 = s_ptr[row], p1 = s_ptr[row + 1];
-    deg = (float)(p1 - p0);
-    own = ld4(a.h_in + node * H + 4 * lr);
-    if (DY) dy = ld4(a.gy_direct + node * H + 4 * lr);
-    cls = a.xcls[node];
-    for (int e = p0; e < p1; ++e) {
-        const int64_t jj = a.idx[e];
-        acc = add4(acc, ld4(a.h_in + jj * H + 4 * lr));
-        if (DY && two) dy = add4(dy, ld4(a.gy_agg + jj * H + 4 * lr));
-    }
-}
-
-template <int H, int RPG, bool DY>
-__device__ __forceinline__ void tile_rows(const StageX3Args& a, int64_t base, int grp, int groups, int lr, const int* s_ptr,
-                                          const int* s_idx, int dmax, float4 (&acc)[RPG], float4 (&own)[RPG], float4 (&dy)[RPG],
-                                          float (&deg)[RPG], int (&cls)[RPG]) {
-    const bool two = DY && a.gy_agg != nullptr;
-    constexpr int D = (RPG >= 4 || DY) ? 2 : 4;      // RPG*D (x2 with DY) row loads in flight per lane: 8
-    if (dmax < (1 << 30) && base + kTileRows <= a.N) {
-        rows_chunked<H, D, RPG, DY>(a, base, grp, groups, lr, s_ptr, s_idx, dmax, two, acc, own, dy, deg, cls);
-    } else {                                         // partial last tile, or an index list beyond LDS
-#pragma unroll
-        for (int rr = 0; rr < RPG; ++rr) {
-            const int row = grp + rr * groups;
-            row_generic<H, DY>(a, base + row, row, lr, s_ptr, two, acc[rr], own[rr], dy[rr], deg[rr], cls[rr]);
-        }
-    }
-}
 
 // gate pre-activations of one tile from the split planes; weights streamed from L2
 template <int H>
@@ -361,18 +98,20 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
         }
 
     int* idx_base = reinterpret_cast<int*>(smem_raw + M::f_idx);
-    int rp = ptr_prefetch(a, blockIdx.x, ntiles);
+    const TileSeq seq = tile_seq(ntiles, a.xcd);
+    int rp = ptr_prefetch(a, seq.at(0), ntiles);
     if (tid <= kTileRows) idx_lds(idx_base, 0).ptr[tid] = rp;
     __syncthreads();
     int ri[kIdxCap / kThreadsF];
     idx_prefetch<kThreadsF>(a, idx_lds(idx_base, 0).ptr, ri);
     idx_commit<kThreadsF>(idx_lds(idx_base, 0).idx, ri);
     tile_dmax(idx_lds(idx_base, 0).ptr, idx_lds(idx_base, 0).dmax());
-    rp = ptr_prefetch(a, (int64_t)blockIdx.x + gridDim.x, ntiles);
+    rp = ptr_prefetch(a, seq.at(1), ntiles);
     __syncthreads();
     int b = 0;
     STAMP_DECL
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, b ^= 1) {
+    for (int it = 0; seq.at(it) < ntiles; ++it, b ^= 1) {
+        const int64_t tile = seq.at(it);
         const int64_t base = tile * kTileRows;
         STAMP_BEGIN;
         // ---- row phase: independent loads only
@@ -399,7 +138,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
         STAMP(1);
         // next tile's indices and the tile after's pointers fly during the dense part + epilogue
         idx_prefetch<kThreadsF>(a, idx_lds(idx_base, b ^ 1).ptr, ri);
-        rp = ptr_prefetch(a, tile + 2 * (int64_t)gridDim.x, ntiles);
+        rp = ptr_prefetch(a, seq.at(it + 2), ntiles);
         tile_dmax(idx_lds(idx_base, b ^ 1).ptr, idx_lds(idx_base, b ^ 1).dmax());
         // ---- dense part: LDS fragments x register-resident weights
         f32x4 ar[S::RTW], az[S::RTW], ani[S::RTW], anh[S::RTW];
@@ -510,41 +249,6 @@ __device__ __forceinline__ void wgrad_flush_x3(const f32x4 (&acc)[WgradX3<H>::TP
     }
 }
 
-// H = 64 with 8 waves: the LDS read rate bounds the weight gradient, so every wave owns a 2x2 block of output tiles
-// of ONE matrix (waves 0-3: Wc against the aggregate planes, waves 4-7: Whh against the own-row planes) and reuses
-// each transposed fragment twice: 8 fragment reads per 12 MFMA triples instead of 12.
-template <int H>
-__device__ __forceinline__ void wgrad_blk_x3(f32x4 (&acc)[4], const __bf16* d_hi, const __bf16* d_lo, const __bf16* x_hi, const __bf16* x_lo) {
-    constexpr int LDP = H + 8;
-    const int b = (threadIdx.x >> 6) & 3;
-    const int it0 = 2 * (b >> 1), jt0 = 2 * (b & 1);
-#pragma unroll 1
-    for (int kk = 0; kk < kTileRows / 32; ++kk) {
-        const int k0 = 32 * kk;
-        bf16x8 bh[2], bl[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr(x_hi, LDP, k0, (jt0 + j) * 16); bl[j] = ldfrag_tr(x_lo, LDP, k0, (jt0 + j) * 16); }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bf16x8 ah = ldfrag_tr(d_hi, LDP, k0, (it0 + i) * 16), al = ldfrag_tr(d_lo, LDP, k0, (it0 + i) * 16);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma_x3(acc[i * 2 + j], ah, al, bh[j], bl[j]);
-        }
-    }
-}
-
-template <int H>
-__device__ __forceinline__ void wgrad_blk_flush_x3(const f32x4 (&acc)[4], float* dW) {
-    const int lane = threadIdx.x & 63, b = (threadIdx.x >> 6) & 3, r = lane & 15, q = lane >> 4;
-    const int it0 = 2 * (b >> 1), jt0 = 2 * (b & 1);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(dW + (int64_t)((it0 + i) * 16 + q * 4 + e) * H + (jt0 + j) * 16 + r, acc[i * 2 + j][e]);
-}
-
 __device__ __forceinline__ void colsum_lds_x3(float v, float* dst) {
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
@@ -612,19 +316,21 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
     __syncthreads();
 
     int* idx_base = reinterpret_cast<int*>(smem_raw + M::b_idx);
-    int rp = ptr_prefetch(a, blockIdx.x, ntiles);
+    const TileSeq seq = tile_seq(ntiles, a.xcd);
+    int rp = ptr_prefetch(a, seq.at(0), ntiles);
     if (tid <= kTileRows) idx_lds(idx_base, 0).ptr[tid] = rp;
     __syncthreads();
     int ri[kIdxCap / kThreadsX3];
     idx_prefetch<kThreadsX3>(a, idx_lds(idx_base, 0).ptr, ri);
     idx_commit<kThreadsX3>(idx_lds(idx_base, 0).idx, ri);
     tile_dmax(idx_lds(idx_base, 0).ptr, idx_lds(idx_base, 0).dmax());
-    rp = ptr_prefetch(a, (int64_t)blockIdx.x + gridDim.x, ntiles);
+    rp = ptr_prefetch(a, seq.at(1), ntiles);
     __syncthreads();
     int b = 0;
     STAMP_DECL
     constexpr int RPG = kTileRows / S::GROUPS;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x, b ^= 1) {
+    for (int it = 0; seq.at(it) < ntiles; ++it, b ^= 1) {
+        const int64_t tile = seq.at(it);
         const int64_t base = tile * kTileRows;
         STAMP_BEGIN;
         // ---- A. row phase (independent loads); operand planes row-major (GEMM A operands) and
@@ -660,7 +366,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
         f32x4 ar[S::RTW][S::HCW], az[S::RTW][S::HCW], ani[S::RTW][S::HCW], anh[S::RTW][S::HCW];
         stage_gemm_x3<H>(a.wpack, wc_hi, whh_hi, agg_hi, agg_lo, hin_hi, hin_lo, ar, az, ani, anh);
         idx_prefetch<kThreadsX3>(a, idx_lds(idx_base, b ^ 1).ptr, ri);          // after the weight fragments (vmcnt is in order); committed at the tile's end
-        rp = ptr_prefetch(a, tile + 2 * (int64_t)gridDim.x, ntiles);
+        rp = ptr_prefetch(a, seq.at(it + 2), ntiles);
         tile_dmax(idx_lds(idx_base, b ^ 1).ptr, idx_lds(idx_base, b ^ 1).dmax());
         STAMP(2);
 #pragma unroll
@@ -928,6 +634,11 @@ extern "C" int mgv_diag_set_stamps(void* p) { g_stamps = static_cast<unsigned lo
 #define MGV_SET_STAMPS(a)
 #endif
 
+static int xcd_tiles() {
+    static const int v = [] { const char* e = getenv("MGV_XCD_TILES"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
+
 extern "C" int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
                                        const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
                                        const float* bhh, const float* ln_w, const float* ln_b, float ln_eps, float* h_out,
@@ -941,6 +652,7 @@ extern "C" int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, cons
     a.N = N; a.h_in = h_in; a.ptr = nbr_ptr; a.idx = nbr_idx; a.xcls = xcls; a.xtab = xtab; a.C = C;
     a.wpack = static_cast<const __bf16*>(wpack_bf16); a.bc = bc; a.bhh = bhh; a.lnw = ln_w; a.lnb = ln_b; a.eps = ln_eps; a.h_out = h_out;
     MGV_SET_STAMPS(a);
+    a.xcd = xcd_tiles();
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (H) {
         case 32: return mgv::launch_fwd_x3<32>(a, st);
@@ -969,6 +681,7 @@ extern "C" int mgv_struct_stage_bwd_x3(int H, int64_t N, const float* h_in, cons
     a.gy_direct = gy_direct; a.gy_agg = gy_agg; a.g_direct_out = g_direct_out; a.g_agg_out = g_agg_out;
     a.dWc = dWc; a.dbc = dbc; a.dWhh = dWhh; a.dbhh = dbhh; a.dxtab = dxtab; a.dlnw = dln_w; a.dlnb = dln_b;
     MGV_SET_STAMPS(a);
+    a.xcd = xcd_tiles();
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (H) {
         case 32: return mgv::launch_bwd_x3<32>(a, st);

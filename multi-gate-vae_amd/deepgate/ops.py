@@ -105,11 +105,38 @@ def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
     return h_out
 
 
+# backward kernel of the bf16x3 half round at H = 64: '2' = register-resident recompute weights, transposed products,
+# slab-reduced (deterministic) parameter gradients (struct_stage_bwd2_x3.hip); '1' = the first kernel (A/B measurements)
+STAGE_BWD = os.environ.get('MGV_STAGE_BWD', '2')
+_WS = {}
+
+
+def _stage_ws(H, N, device):
+    """Scratch slab of mgv_struct_stage_bwd2_x3 (one per device, grown on demand; contents are never read across calls)."""
+    n = _hip.call_value('mgv_struct_stage_bwd2_ws_floats', H, N)
+    ws = _WS.get(device)
+    if ws is None or ws.numel() < n:
+        ws = torch.empty(max(n, 1), dtype=F32, device=device)
+        _WS[device] = ws
+    return ws
+
+
 def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, gy_direct, gy_agg,
                      grads, need_input_grad=True, wpack=None):
     """`grads` = dict of fp32 accumulators (dWc, dbc, dWhh, dbhh, dxtab, dln_w, dln_b), added to."""
     N, H = h_in.shape
     check(gy_direct, F32, 'gy_direct'); check(gy_agg, F32, 'gy_agg')
+    if use_x3(H) and H == 64 and STAGE_BWD == '2':
+        g_direct = torch.empty_like(h_in) if need_input_grad else None
+        g_agg = torch.empty_like(h_in) if need_input_grad else None
+        wpack = stage_wpack(Wc, Whh) if wpack is None else wpack
+        ws = _stage_ws(H, N, h_in.device)
+        _hip.call('mgv_struct_stage_bwd2_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
+                  xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(gy_direct),
+                  ptr(gy_agg), ptr(g_direct), ptr(g_agg), ptr(grads['dWc']), ptr(grads['dbc']), ptr(grads['dWhh']),
+                  ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')),
+                  ptr(ws), ws.numel())
+        return g_direct, g_agg
     if use_x3(H):
         g_direct = torch.empty_like(h_in) if need_input_grad else None
         g_agg = torch.empty_like(h_in) if need_input_grad else None
