@@ -96,22 +96,26 @@ class FlatAdam(torch.optim.Optimizer):
         return loss
 
     # ---- torch.optim.Adam-compatible checkpoint format ----------------------------------------------
+    def _indexed(self):
+        """(index in the parameter group, parameter, flat offset) of every trained parameter.  torch.optim.Adam numbers
+        its state by position in the group, frozen parameters included: the checkpoint format follows that."""
+        offs = iter(self._flat['offsets'])
+        return [(i, p, next(offs)) for i, p in enumerate(self.param_groups[0]['params']) if p.requires_grad]
+
     def state_dict(self):
-        ps = self._params()
         state = {}
         if self._flat is not None and self._step > 0:
-            for i, (p, off) in enumerate(zip(ps, self._flat['offsets'])):
+            for i, p, off in self._indexed():
                 k = p.numel()
                 state[i] = {'step': torch.tensor(float(self._step)),
                             'exp_avg': self._flat['m'][off:off + k].view(p.shape).clone(),
                             'exp_avg_sq': self._flat['v'][off:off + k].view(p.shape).clone()}
         group = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
-        group['params'] = list(range(len(ps)))
+        group['params'] = list(range(len(self.param_groups[0]['params'])))
         return {'state': state, 'param_groups': [group]}
 
     def _apply_state(self, state):
-        ps = self._params()
-        for i, (p, off) in enumerate(zip(ps, self._flat['offsets'])):
+        for i, p, off in self._indexed():
             st = state.get(i, state.get(str(i)))
             if st is None:
                 continue
@@ -128,4 +132,6 @@ class FlatAdam(torch.optim.Optimizer):
         if self._flat is not None and self._is_flat():
             self._apply_state(sd['state'])
         else:
-            self._pending_state = sd['state']
+            # applied at the first flatten; copied now: torch.optim state_dicts alias the live optimiser's tensors
+            self._pending_state = {k: {kk: (vv.detach().clone() if torch.is_tensor(vv) else vv) for kk, vv in st.items()}
+                                   for k, st in sd['state'].items()}

@@ -83,7 +83,9 @@ class NpzParser:
     (parser.py:22-41).  The parsed list is cached as `<data_dir>/inmemory_mgv/<type>.npz` like the reference's
     `inmemory/data.pt`."""
 
-    def __init__(self, data_dir, circuit_path, label_path, circuit_type, random_shuffle=True, trainval_split=0.9, seed=None):
+    def __init__(self, data_dir, circuit_path, label_path, circuit_type, random_shuffle=True, trainval_split=0.9, seed=0):
+        """`seed` fixes the shuffle and therefore the train/val cut: every rank of a distributed job must hold the SAME
+        ordered lists (GraphLoader strides them by rank), so the default is a constant, not entropy."""
         self.data_dir, self.circuit_type = data_dir, circuit_type
         graphs = self._load(data_dir, circuit_path, label_path, circuit_type)
         if random_shuffle:
@@ -98,8 +100,22 @@ class NpzParser:
     @staticmethod
     def _load(data_dir, circuit_path, label_path, circuit_type):
         cache = os.path.join(data_dir, 'inmemory_mgv', '%s.npz' % circuit_type)
+        rank, dist = 0, None
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                rank = dist.get_rank()
+            else:
+                dist = None
+        except ImportError:
+            dist = None
+        if dist is not None and rank != 0:
+            dist.barrier()                      # rank 0 parses and publishes the cache, the others read it
         if os.path.exists(cache):
-            return list(np.load(cache, allow_pickle=True)['graphs'])
+            graphs = list(np.load(cache, allow_pickle=True)['graphs'])
+            if dist is not None and rank == 0:
+                dist.barrier()
+            return graphs
         circuits = np.load(circuit_path, allow_pickle=True)['circuits'].item()
         labels = None if circuit_type == 'aig' else np.load(label_path, allow_pickle=True)['labels'].item()
         tt_key = 'tt_sim' if circuit_type == 'aig' else 'tt_dis'
@@ -116,6 +132,10 @@ class NpzParser:
         os.makedirs(os.path.dirname(cache), exist_ok=True)
         arr = np.empty(len(graphs), dtype=object)
         arr[:] = graphs
-        np.savez(cache, graphs=arr)
+        tmp = cache + '.tmp.%d.npz' % os.getpid()          # published atomically: readers never see a half-written file
+        np.savez(tmp, graphs=arr)
+        os.replace(tmp, cache)
         print('[INFO] Inmemory dataset save: ', cache)
+        if dist is not None and rank == 0:
+            dist.barrier()
         return graphs

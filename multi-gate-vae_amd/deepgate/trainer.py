@@ -6,6 +6,7 @@ step), only rank 0 writes checkpoints, step metrics come from four device-side c
 host copy of every edge prediction, and the dead N x N negative mask of the edge split is never built.
 """
 import os
+import sys
 import time
 
 import numpy as np
@@ -77,17 +78,25 @@ class Trainer():
         if self.distributed:
             if 'LOCAL_RANK' in os.environ:
                 self.local_rank = int(os.environ['LOCAL_RANK'])
-            dev_index = self.local_rank % max(torch.cuda.device_count(), 1)   # one rank per GPU (wraps only in rehearsals)
+            backend = os.environ.get('MGV_DIST_BACKEND', 'nccl')      # 'nccl' is RCCL on ROCm; 'gloo' = single-GPU rehearsal
+            ndev = torch.cuda.device_count()
+            if self.local_rank >= ndev and backend == 'nccl':
+                raise RuntimeError('rank with LOCAL_RANK=%d but only %d GPU(s) visible: one rank per GPU '
+                                   '(MGV_DIST_BACKEND=gloo stacks ranks on the visible GPUs for rehearsals)' % (self.local_rank, ndev))
+            dev_index = self.local_rank % max(ndev, 1)
             self.device = 'cuda:%d' % dev_index
             torch.cuda.set_device(dev_index)
             if not torch.distributed.is_initialized():
-                # backend 'nccl' is RCCL on ROCm; rendezvous from the torchrun environment
-                torch.distributed.init_process_group(backend=os.environ.get('MGV_DIST_BACKEND', 'nccl'), init_method='env://')
+                # rendezvous from the torchrun environment
+                if backend == 'nccl':
+                    torch.distributed.init_process_group(backend='nccl', init_method='env://', device_id=torch.device(self.device))
+                else:
+                    torch.distributed.init_process_group(backend=backend, init_method='env://')
             self.world_size = torch.distributed.get_world_size()
             self.rank = torch.distributed.get_rank()
-            print('Training in distributed mode. Device {}, Process {:}, total {:}.'.format(self.device, self.rank, self.world_size))
+            print('Training in distributed mode. Device {}, Process {:}, total {:}.'.format(self.device, self.rank, self.world_size), file=sys.stderr)
         else:
-            print('Training in single device: ', self.device)
+            print('Training in single device: ', self.device, file=sys.stderr)
         self.reg_loss = ops.l1_loss                     # nn.L1Loss() of the reference, on the HIP kernel
         self.model = model.to(self.device)
         self.optimizer = FlatAdam(self.model.parameters(), lr=self.lr)

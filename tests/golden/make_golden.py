@@ -16,6 +16,11 @@ Fixture families:
   g4_vae.npz      DirectedGVAE.sample with the two randn_like draws replayed, KL per trainer.py:146-147
   g5_cfg1.npz     3 consecutive run_batch+Adam steps on BASELINE config 1 with dropout active
                   (loose trajectory check only)
+  g6_loader.npz   the reference's own parsers on raw MixGate-layout circuits with shuffled node ids:
+                  parser_func.parse_pyg_mlpgate (aig, [2,E] layout) and parser_func_others.parse_pyg_mlpgate
+                  (xmg, [E,2] layout) incl. return_order_info levels (utils/dag_utils.py:10-37,80-88)
+  g7_ckpt.npz +   a checkpoint written by the reference's Trainer.save after one Adam step (g1 aig setup),
+  g7_ckpt_ref_aig.pth  the losses / parameters of the reference's NEXT step after Trainer.load of that file
 """
 import argparse
 import importlib.util
@@ -348,6 +353,86 @@ def g5_cfg1():
     return out
 
 
+def _raw_circuit(ctype, seed):
+    """A synthetic circuit in the raw MixGate layout with SHUFFLED node ids (levels are not contiguous id ranges)."""
+    g = syn.make_graph(ctype, 100, 9, seed, n_inputs=10)
+    n = g['num_nodes']
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    perm = rng.permutation(n)                       # new id of old node i
+    inv = np.argsort(perm)
+    gate = g['gate'].reshape(-1)[inv].astype(np.int64)
+    x = np.stack([np.arange(n), gate], 1).astype(np.float64)          # column 0 = node id, column 1 = gate id
+    ei = perm[g['edge_index']]
+    order = rng.permutation(ei.shape[1])            # edge order shuffled too
+    ei = ei[:, order]
+    tp = perm[g['tt_pair_index']]
+    return x, ei, g['prob'].reshape(-1)[inv].astype(np.float32), g['tt_sim'], tp
+
+
+def g6_loader():
+    from deepgate import parser_func, parser_func_others
+    out = {}
+    for tag, ctype, fn, transposed in (('aig', 'aig', parser_func.parse_pyg_mlpgate, False),
+                                       ('xmg', 'xmg', parser_func_others.parse_pyg_mlpgate, True)):
+        x, ei, prob, tts, tp = _raw_circuit(ctype, 9700)
+        ei_in = ei.T.copy() if transposed else ei
+        tp_in = tp.T.copy() if transposed else tp
+        g = fn(x, ei_in, prob, tts, tp_in)
+        out.update({tag + '_in_x': x, tag + '_in_edge_index': ei_in, tag + '_in_prob': prob, tag + '_in_tt_sim': tts,
+                    tag + '_in_tt_pair_index': tp_in,
+                    tag + '_x': g.x.numpy(), tag + '_edge_index': g.edge_index.numpy(),
+                    tag + '_forward_level': g.forward_level.numpy(), tag + '_forward_index': g.forward_index.numpy(),
+                    tag + '_backward_level': g.backward_level.numpy(), tag + '_prob': g.prob.numpy(),
+                    tag + '_tt_pair_index': g.tt_pair_index.numpy(), tag + '_tt_sim': g.tt_sim.numpy()})
+        if hasattr(g, 'gate') and g.gate is not None:
+            out[tag + '_gate'] = g.gate.numpy()
+    return out
+
+
+def g7_ckpt():
+    """Reference Trainer: step, save, (fresh trainer) load, step -> what a drop-in must reproduce from the same file."""
+    ctype, H, R, seed = 'aig', 16, 2, 11
+    graphs = [syn.make_graph(ctype, 48, 7, 9100, n_inputs=6), syn.make_graph(ctype, 40, 7, 9200, n_inputs=5)]
+    batch = syn.collate(graphs)
+    neg = torch.from_numpy(batch['neg_edge_index'])
+    MODEL_MODULES[ctype].negative_sampling = lambda *a, **k: neg
+
+    def step(tr):
+        tr.optimizer.zero_grad()
+        torch.manual_seed(seed + 7)
+        ls = tr.run_batch(to_data(batch))
+        (ls['recon_loss'] + 4.0 * ls['prob_loss'] + 4.0 * ls['func_loss']).backward()
+        tr.optimizer.step()
+        return [float(ls['recon_loss']), float(ls['prob_loss']), float(ls['func_loss'])]
+
+    model = build_model(ctype, H, R, seed)
+    model.train(); set_dropout(model, 0.0)
+    tr = make_trainer(model, [1.0, 4.0, 4.0], 1e-4)
+    l1 = step(tr)
+    tr.model_epoch = 3
+    path = os.path.join(HERE, 'g7_ckpt_ref_aig.pth')
+    tr.save(path)
+    model2 = build_model(ctype, H, R, seed + 100)          # different init: everything must come from the file
+    model2.train(); set_dropout(model2, 0.0)
+    tr2 = make_trainer(model2, [1.0, 4.0, 4.0], 1e-4)
+    tr2.load(path)
+    l2 = step(tr2)
+    out = {'meta_type': np.array(ctype), 'meta_H': np.array(H), 'meta_R': np.array(R), 'meta_epoch': np.array(3),
+           'losses_step1': np.asarray(l1), 'losses_step2': np.asarray(l2)}
+    for k in ('x', 'edge_index', 'gate', 'forward_level', 'forward_index', 'prob', 'tt_pair_index', 'tt_sim', 'neg_edge_index', 'graph_ptr'):
+        out['in_' + k] = batch[k]
+    out.update(sd_arrays('saved_', model.state_dict()))
+    out.update(sd_arrays('after2_', model2.state_dict()))
+    osd = tr2.optimizer.state_dict()['state']
+    names = [k for k, _ in model2.named_parameters()]
+    for i, k in enumerate(names):
+        if i in osd:
+            out['adam2_exp_avg_' + k] = osd[i]['exp_avg'].numpy().copy()
+            out['adam2_exp_avg_sq_' + k] = osd[i]['exp_avg_sq'].numpy().copy()
+            out['adam2_step'] = np.array(float(osd[i]['step']))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', default='')
@@ -360,6 +445,8 @@ def main():
     jobs['g3_ops'] = g3_ops
     jobs['g4_vae'] = g4_vae
     jobs['g5_cfg1'] = g5_cfg1
+    jobs['g6_loader'] = g6_loader
+    jobs['g7_ckpt'] = g7_ckpt
     for name, fn in jobs.items():
         if a.only and a.only not in name:
             continue

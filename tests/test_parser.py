@@ -108,3 +108,67 @@ def test_parsed_graphs_carry_no_fixed_negatives(tmp_path):
     batch = deepgate.CircuitBatch.from_arrays(syn.collate([p, p]))
     assert getattr(batch, 'neg_edge_index', None) is None
     assert hasattr(deepgate.CircuitBatch.from_arrays(syn.collate([g, g])), 'neg_edge_index')     # the synthetic ones keep theirs
+
+
+# ---- the reference's OWN parser output (tests/golden/g6_loader.npz, written by make_golden.py from
+#      parser_func.parse_pyg_mlpgate / parser_func_others.parse_pyg_mlpgate incl. return_order_info)
+@pytest.mark.parametrize('tag,ctype', [('aig', 'aig'), ('xmg', 'xmg')])
+def test_parse_graph_equals_the_reference_parser_output(tag, ctype):
+    import os
+    from conftest import GOLDEN
+    from deepgate.parser import parse_graph
+    z = np.load(os.path.join(GOLDEN, 'g6_loader.npz'))
+    x = z[tag + '_in_x']
+    g = parse_graph(x, z[tag + '_in_edge_index'], z[tag + '_in_prob'], z[tag + '_in_tt_sim'], z[tag + '_in_tt_pair_index'], ctype,
+                    gate=x[:, 1:2] if ctype == 'aig' else None)
+    assert np.array_equal(g['x'], z[tag + '_x'])
+    assert np.array_equal(g['edge_index'], z[tag + '_edge_index'])
+    assert np.array_equal(g['forward_level'], z[tag + '_forward_level'])          # dag_utils.top_sort of the reference
+    assert np.array_equal(g['forward_index'], z[tag + '_forward_index'])
+    assert np.array_equal(g['tt_pair_index'], z[tag + '_tt_pair_index'])
+    np.testing.assert_array_equal(g['tt_sim'], z[tag + '_tt_sim'].astype(np.float32))
+    np.testing.assert_array_equal(g['prob'], z[tag + '_prob'].astype(np.float32))
+    if tag + '_gate' in z.files:
+        np.testing.assert_array_equal(g['gate'], z[tag + '_gate'])
+    # the node ids of the fixture are shuffled: levels must not be monotone in the id (the test would otherwise be vacuous)
+    assert (np.diff(g['forward_level']) < 0).any()
+
+
+def test_backward_levels_of_the_reference_are_the_levels_of_the_flipped_graph():
+    import os
+    from conftest import GOLDEN
+    from deepgate.parser import forward_levels
+    z = np.load(os.path.join(GOLDEN, 'g6_loader.npz'))
+    ei = z['aig_edge_index']
+    assert np.array_equal(forward_levels(ei[::-1], z['aig_x'].shape[0]), z['aig_backward_level'])
+
+
+def test_split_is_identical_on_every_rank_and_loader_shards_are_disjoint(tmp_path):
+    """Two processes that build NpzParser independently (as the ranks of a distributed job do) must hold the same ordered
+    train/val lists; GraphLoader then strides them by rank: disjoint shards that cover the list."""
+    from deepgate.parser import NpzParser
+    from deepgate.trainer import GraphLoader
+    rng = np.random.default_rng(3)
+    circuits = {}
+    for k in range(23):
+        n = 12 + k
+        ei, gate = _random_dag(rng, n, 3, max_fanin=2)
+        gate = np.where(gate == 3, 1, gate)                       # aig ids: AND = 1, NOT = 2
+        x = np.stack([np.arange(n), gate], 1).astype(np.float64)
+        circuits['c%02d' % k] = {'x': x, 'edge_index': ei, 'gate': gate.reshape(-1, 1).astype(np.float32),
+                                 'prob': rng.random(n).astype(np.float32), 'tt_pair_index': rng.integers(0, n, (2, 5)),
+                                 'tt_sim': rng.random(5).astype(np.float32)}
+    np.savez(tmp_path / 'graphs.npz', circuits=np.array(circuits, dtype=object))
+    a = NpzParser(str(tmp_path), str(tmp_path / 'graphs.npz'), '', 'aig')
+    b = NpzParser(str(tmp_path), str(tmp_path / 'graphs.npz'), '', 'aig')       # second "rank": reads the published cache
+    names = lambda lst: [g['name'] for g in lst]
+    assert names(a.train_dataset) == names(b.train_dataset) and names(a.val_dataset) == names(b.val_dataset)
+    assert not set(names(a.train_dataset)) & set(names(a.val_dataset))
+    assert not [f for f in (tmp_path / 'inmemory_mgv').iterdir() if '.tmp.' in f.name]      # cache was published atomically
+    world = 2
+    shards = [GraphLoader(a.train_dataset, 2, shuffle=False, rank=r, world_size=world)._indices() for r in range(world)]
+    n = len(a.train_dataset)
+    assert len(shards[0]) == len(shards[1]) == (n + 1) // 2
+    flat = shards[0] + shards[1]
+    assert set(flat) == set(range(n))                         # every graph is trained on by exactly one rank...
+    assert len(flat) - len(set(flat)) == (n + 1) // 2 * 2 - n  # ...except the wrap-around padding of DistributedSampler
