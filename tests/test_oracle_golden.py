@@ -227,3 +227,36 @@ def test_fast_sweep_equals_plain_autograd_sweep(name):
             gb = p2[k].grad if p2[k].grad is not None else torch.zeros_like(p2[k])
             scale = max(1e-6, float(ga.abs().max()))
             np.testing.assert_allclose(gb.numpy(), ga.numpy(), rtol=1e-4, atol=1e-5 * scale + 1e-7, err_msg=k)
+
+
+# ---- the literal variant (oracle/ref_cpu_literal.py: per-node subgraph scans, dense N x N mask, full-state level loop)
+@pytest.mark.parametrize('name', ['g1_' + t for t in TYPES])
+def test_literal_oracle_matches_reference_fixtures_and_the_vectorised_oracle(name):
+    from oracle import ref_cpu_literal as L
+    z = load(name)
+    ctype, Rr, p, batch = _model_case(z)
+    with torch.no_grad():
+        hs, hf, s, t = L.model_forward(p, ctype, batch, Rr, Rr)
+    close(hs, z['eval_hs'], 5e-5, 2e-5)
+    close(hf, z['eval_hf'], 5e-5, 2e-5)
+    bn = {k: v.clone() for k, v in p.items() if 'running_' in k}
+    torch.manual_seed(0)
+    ls = L.run_batch(p, ctype, batch, training=True, bn_state=bn, p_drop=0.0, s_rounds=Rr, t_rounds=Rr)
+    close(ls['recon_loss'], z['train_recon'], 1e-5)          # the edge permutation does not move the mean
+    close(ls['prob_loss'], z['train_prob_loss'], 1e-5)
+    close(ls['func_loss'], z['train_func_loss'], 1e-5)
+    R.weighted_loss(ls, z['meta_weights']).backward()
+    for k, v in p.items():
+        if v.requires_grad and v.grad is not None and ('grad_' + k) in z.files:
+            ref = z['grad_' + k]
+            np.testing.assert_allclose(v.grad.numpy(), ref, rtol=2e-4, atol=2e-4 * float(np.abs(ref).max()) + 2e-6, err_msg=k)
+
+
+def test_literal_subgraph_and_edge_split_semantics():
+    from oracle import ref_cpu_literal as L
+    ei = torch.tensor([[0, 1, 2, 0, 3, 1], [3, 3, 4, 4, 5, 5]])
+    sub = L.subgraph(torch.tensor([5, 3]), ei, dim=1)
+    assert sub.tolist() == [[3, 1, 0, 1], [5, 5, 3, 3]]       # target order, original edge order inside a target
+    torch.manual_seed(1)
+    tp = L.general_train_test_split_edges(ei, 6)
+    assert sorted(map(tuple, tp.t().tolist())) == sorted(map(tuple, ei.t().tolist()))

@@ -1,49 +1,101 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch of the hot kernels from two rocprofv3 counter passes.
+"""Per-launch hardware counters of the hot kernels from rocprofv3 counter passes (run on the GPU box, counters only:
+no trace domains beside --pmc; the program goes directly after `--`).
 
-Run on the GPU box (separate passes: FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md §HBM):
+  traffic mode (L2 -> fabric bytes; FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md §HBM):
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o p -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o p -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
+    python3 tools/pmc_traffic.py traffic <fetch csv> <write csv> N > profiles/rNN_pmc_traffic.json
+  busy mode (matrix / vector pipe occupancy):
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE ... -- python3 bench.py ...
+    python3 tools/pmc_traffic.py busy <csv> N > profiles/rNN_pmc_mfma.json
 
-    cd /tmp && export TMPDIR=/tmp
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o p -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline
-    rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o p -- python3 $REPO/bench.py --steps 1 --warmup 1 --no-cpu-baseline
-    python3 $REPO/tools/pmc_traffic.py /tmp/pmc_f/p_counter_collection.csv /tmp/pmc_w/p_counter_collection.csv N > traffic.json
-
-Counters are KiB; FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes).  Launches much smaller
-than a kernel's largest (the (degree, class) table launches of the struct stage) are left out of the average."""
+FETCH_SIZE / WRITE_SIZE are KiB of L2 <-> fabric traffic (TCC_EA0 requests): Infinity-Cache hits are INCLUDED, so this is an
+upper bound on HBM bytes, not HBM bytes.  FETCH_SIZE is doubled (gfx950 tallies 128-byte read requests at 64 bytes).
+Launches much smaller than a kernel's largest (the (degree, class) table launches of the struct stage) are left out."""
 import collections
 import csv
 import json
 import sys
 
-LAUNCHER = {'k_struct_stage_fwd_x3': 'mgv_struct_stage_fwd_x3', 'k_struct_stage_bwd_x3': 'mgv_struct_stage_bwd_x3',
+LAUNCHER = {'k_struct_stage_fwd_x3': 'mgv_struct_stage_fwd_x3', 'k_struct_stage_bwd2_x3': 'mgv_struct_stage_bwd2_x3',
+            'k_struct_stage_bwd_x3': 'mgv_struct_stage_bwd_x3',
             'k_level_fwd_x3': 'mgv_func_sweep_fwd_x3 (one level)', 'k_level_bwd_x3': 'mgv_func_sweep_bwd_x3 (one level)',
+            'k_sweep_fwd_x3': 'mgv_func_sweep_fwd_x3', 'k_sweep_bwd_x3': 'mgv_func_sweep_bwd_x3',
             'k_sweep_wgrad_x3': 'mgv_func_sweep_bwd_x3 (weight gradient, one slot)', 'k_recon_bwd_pull2': 'mgv_recon_loss_bwd_csr',
-            'k_recon<': 'mgv_recon_loss_fwd', 'k_class_pull_sum': 'mgv_class_pull_sum'}
+            'k_recon<': 'mgv_recon_loss_fwd', 'k_class_pull_sum': 'mgv_class_pull_sum', 'k_linear_fwd_x3': 'mgv_linear_fwd_x3'}
 
 
 def per_kernel(path):
-    vals = collections.defaultdict(list)
+    """{kernel name: {counter: [value per dispatch]}} (values of one dispatch summed over its rows)."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
     for r in csv.DictReader(open(path)):
-        vals[r['Kernel_Name']].append(float(r['Counter_Value']))
-    return vals
+        acc[r['Kernel_Name']][r['Counter_Name']][r.get('Dispatch_Id', r.get('Correlation_Id', '0'))] += float(r['Counter_Value'])
+    return {k: {c: list(d.values()) for c, d in v.items()} for k, v in acc.items()}
+
+
+def launcher_of(name):
+    return next((v for k, v in LAUNCHER.items() if k in name), None)
+
+
+def big(vals, ref=None):
+    ref = ref if ref is not None else vals
+    m = max(ref) if ref else 0.0
+    return [v for v, rv in zip(vals, ref) if rv >= 0.5 * m] if m > 0 else vals
+
+
+def traffic(fetch_csv, write_csv, N):
+    fetch, write = per_kernel(fetch_csv), per_kernel(write_csv)
+    out = {'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (bench.py --steps 1 --warmup 1, config 2); KiB units; '
+                   'FETCH_SIZE doubled (gfx950 tallies 128-byte read requests at 64 bytes); L2<->fabric traffic, Infinity-Cache hits '
+                   'included: an upper bound on HBM bytes; launches under half of a kernel\'s largest are left out', 'N': N, 'kernels': {}}
+    for name, cs in fetch.items():
+        key = launcher_of(name)
+        if key is None or 'FETCH_SIZE' not in cs:
+            continue
+        fv = big(cs['FETCH_SIZE'])
+        wv = big(write.get(name, {}).get('WRITE_SIZE', [0.0]))
+        f, w = sum(fv) / len(fv), sum(wv) / max(len(wv), 1)
+        out['kernels'][key] = {'FETCH_SIZE_KiB_avg': f, 'WRITE_SIZE_KiB_avg': w, 'launches': len(fv), 'fabric_bytes_per_launch': (2 * f + w) * 1024}
+    return out
+
+
+def busy(path, N):
+    data = per_kernel(path)
+    out = {'note': 'rocprofv3 --pmc pass of bench.py --steps 1 --warmup 1 (config 2); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES): '
+                   'share of SIMD cycles with the matrix pipe busy; valu_busy = 4 x SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES / 4 (quad-cycles '
+                   'of vector issue per SIMD cycle); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves parked on s_waitcnt / barriers)', 'N': N, 'kernels': {}}
+    for name, cs in data.items():
+        key = launcher_of(name)
+        if key is None or 'SQ_BUSY_CU_CYCLES' not in cs:
+            continue
+        ref = cs['SQ_BUSY_CU_CYCLES']
+        tot = lambda c: sum(big(cs[c], ref)) if c in cs else None
+        cu = tot('SQ_BUSY_CU_CYCLES')
+        rec = {'launches': len(big(ref)), 'SQ_BUSY_CU_CYCLES': cu}
+        for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY',
+                  'SQ_INSTS_VALU_MFMA_MOPS_BF16', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'GRBM_GUI_ACTIVE'):
+            if c in cs:
+                rec[c] = tot(c)
+        if cu and 'SQ_VALU_MFMA_BUSY_CYCLES' in rec:
+            rec['mfma_busy'] = rec['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * cu)
+        if cu and 'SQ_ACTIVE_INST_VALU' in rec:
+            rec['valu_busy'] = rec['SQ_ACTIVE_INST_VALU'] * 4.0 / (4.0 * cu)
+        if rec.get('SQ_WAVE_CYCLES') and 'SQ_WAIT_ANY' in rec:
+            rec['wait_share'] = rec['SQ_WAIT_ANY'] / rec['SQ_WAVE_CYCLES']
+        out['kernels'][key] = rec
+    return out
 
 
 def main():
-    fetch, write, N = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), int(sys.argv[3])
-    out = {'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (bench.py --steps 1 --warmup 1, config 2); KiB units; '
-                   'FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide reads on gfx950; launches under half of a kernel\'s '
-                   'largest are left out (table-sized launches of the first half round)', 'N': N, 'kernels': {}}
-    for name, fv in fetch.items():
-        key = next((v for k, v in LAUNCHER.items() if k in name), None)
-        if key is None:
-            continue
-        wv = write.get(name, [])
-        big_f = [v for v in fv if v >= 0.5 * max(fv)]
-        big_w = [v for v in wv if v >= 0.5 * max(wv)] if wv and max(wv) > 0 else [0.0]
-        f, w = sum(big_f) / len(big_f), sum(big_w) / len(big_w)
-        out['kernels'][key] = {'FETCH_SIZE_KiB_avg': f, 'WRITE_SIZE_KiB_avg': w, 'launches': len(big_f),
-                               'hbm_bytes_per_launch': (2 * f + w) * 1024}
-    json.dump(out, sys.stdout, indent=1)
+    mode = sys.argv[1]
+    if mode == 'traffic':
+        res = traffic(sys.argv[2], sys.argv[3], int(sys.argv[4]))
+    elif mode == 'busy':
+        res = busy(sys.argv[2], int(sys.argv[3]))
+    else:
+        raise SystemExit(__doc__)
+    json.dump(res, sys.stdout, indent=1)
 
 
 if __name__ == '__main__':
