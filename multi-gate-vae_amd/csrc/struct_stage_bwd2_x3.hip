@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
     const __bf16 *wr_hi_p = wr_hi_p_, *wr_lo_p = wr_lo_p_, *wd_hi_p = wd_hi_p_, *wd_lo_p = wd_lo_p_;
     // ---- persistent accumulators
     f32x4 gW[3][4];                         // 2x2 block of this wave's matrix, per gate (wgrad_blk_x3)
-    f32x4 gX[2];                            // bias-type gradients of planes p = 2m, 2m+1, gate-column tile wc
+    f32x4 gX[2];                            // bias-type gradients of planes p = m (pp 0) and 2 + m (pp 1), gate-column tile wc
     float slw[4], slb[4];                   // LayerNorm affine gradients of columns c0..c0+3 over this lane's nodes
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
 #pragma unroll
     for (int e = 0; e < 4; ++e) { slw[e] = 0.f; slb[e] = 0.f; }
 
+    // (static priority for the second-dispatched half, waves 4-7, only swaps which half waits at the barriers: measured zero-sum)
     const TileSeq seq = tile_seq(ntiles, a.xcd);
     int rp = ptr_prefetch(a, seq.at(0), ntiles);
     if (tid <= kTileRows) idx_lds(idx_base, 0).ptr[tid] = rp;
@@ -338,32 +339,46 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                     dgo[2] = dhz[0]; dgo[3] = dhz[1];
                 }
             }
+            // Weight gradients of all three gates in ONE pass over the tile's two 32-row k-steps: the transposed fragments of the
+            // wave's two input-column tiles (and of the [deg, onehot, 1] columns) are read once per k-step and serve every gate;
+            // the bias-type tile (gX) reuses the gate-gradient fragment the 2x2 block loads anyway (its row tile wc is it0 + (wc & 1),
+            // its planes p = 2 pp + m are among the three this wave's matrix reads).  The dgrad fragments of each half leave L2 in
+            // front of one k-step of these MFMAs.
+            const int it0 = 2 * (wc >> 1), jt0 = 2 * (wc & 1), ig = wc & 1;
+            bf16x8 wd_hi[3], wd_lo[3];
+            asm volatile("" : "+v"(wd_hi_p), "+v"(wd_lo_p));
+            if (need_dgrad) {
 #pragma unroll
+                for (int k = 0; k < 3; ++k) { wd_hi[k] = ldfrag(wd_hi_p + k * 512); wd_lo[k] = ldfrag(wd_lo_p + k * 512); }
+            }
+#pragma unroll 1
             for (int half = 0; half < 2; ++half) {
-                bf16x8 wd_hi[3], wd_lo[3];
-                asm volatile("" : "+v"(wd_hi_p), "+v"(wd_lo_p));
-                if (need_dgrad) {
+                const int k0 = 32 * half;
+                bf16x8 bh[2], bl[2];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { wd_hi[k] = ldfrag(wd_hi_p + (3 * half + k) * 512); wd_lo[k] = ldfrag(wd_lo_p + (3 * half + k) * 512); }
-                }
-                if (half == 0) {
+                for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr(x_hi, LDP, k0, (jt0 + j) * 16); bl[j] = ldfrag_tr(x_lo, LDP, k0, (jt0 + j) * 16); }
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) wgrad_blk_x3<H>(gW[g], s_dg + g * 2 * PE, s_dg + g * 2 * PE + PE, x_hi, x_lo);
-                } else {
-                    const __bf16* pn = s_dg + (2 + m) * 2 * PE;           // n gate: Wc takes dan, Whh takes dan * r
-                    wgrad_blk_x3<H>(gW[2], pn, pn + PE, x_hi, x_lo);
+                for (int g = 0; g < 3; ++g) {
+                    const int p = g == 2 ? 2 + m : g;
+                    const __bf16* ph = s_dg + p * 2 * PE;
 #pragma unroll
-                    for (int pp = 0; pp < 2; ++pp) {
-                        const __bf16* ph = s_dg + (2 * m + pp) * 2 * PE;
-                        const __bf16* pl = ph + PE;
+                    for (int i = 0; i < 2; ++i) {
+                        const bf16x8 ah = ldfrag_tr(ph, LDP, k0, (it0 + i) * 16), al = ldfrag_tr(ph + PE, LDP, k0, (it0 + i) * 16);
 #pragma unroll
-                        for (int ks = 0; ks < kTileRows / 32; ++ks)
-                            mma_x3(gX[pp], ldfrag_tr(ph, LDP, 32 * ks, wc * 16), ldfrag_tr(pl, LDP, 32 * ks, wc * 16),
-                                   ldfrag_tr(xe_hi, XLD, 32 * ks, 0), ldfrag_tr(xe_lo, XLD, 32 * ks, 0));
+                        for (int j = 0; j < 2; ++j) mma_x3(gW[g][i * 2 + j], ah, al, bh[j], bl[j]);
+                        if (i == ig && (g == 2 || g == m)) mma_x3(gX[g == 2 ? 1 : 0], ah, al, ldfrag_tr(xe_hi, XLD, k0, 0), ldfrag_tr(xe_lo, XLD, k0, 0));
                     }
                 }
-                // dgrad of this wave's matrix over all four row tiles: m = 0 -> dagg^T = WcT (dar, daz, dan); m = 1 -> dhd^T = dh*z + WhhT (dar, daz, dan*r)
-                if (need_dgrad) {
+            }
+            STAMP(8);
+            if (need_dgrad) {
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (half == 1) {
+                        asm volatile("" : "+v"(wd_hi_p), "+v"(wd_lo_p));
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { wd_hi[k] = ldfrag(wd_hi_p + (3 + k) * 512); wd_lo[k] = ldfrag(wd_lo_p + (3 + k) * 512); }
+                    }
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         const int ks = 3 * half + k;
@@ -377,7 +392,6 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                         }
                     }
                 }
-                if (half == 0) { STAMP(8); }
             }
         }
         STAMP(9);
@@ -395,16 +409,6 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
         STAMP(11);
         __syncthreads();                                    // (6) output tiles, next tile's indices
         STAMP(12);
-        if (seq.at(it + 1) < ntiles) {          // the next tile's recompute fragments: requested now, used after its barrier (1)
-            asm volatile("" : "+v"(wr_hi_p), "+v"(wr_lo_p));      // opaque per tile: keeps the (loop-invariant) loads inside the loop
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    wr_hi[ks][g] = ldfrag(wr_hi_p + (g * 8 + ks) * 512);
-                    wr_lo[ks][g] = ldfrag(wr_lo_p + (g * 8 + ks) * 512);
-                }
-        }
         if (need_dgrad) {
             LANE_IDS
 #pragma unroll
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(256) void k_struct_stage_bwd2_reduce(B2RedArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) dW[((it0 + i) * 16 + q * 4 + e) * H + (jt0 + j) * 16 + r] += v[e];
     } else {                                                  // gX of plane p: gate column wc*16 + 4q + e against xe column r
-        const int p = 2 * m + (slot - 12), g = p < 2 ? p : 2;
+        const int p = 2 * (slot - 12) + m, g = p < 2 ? p : 2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int i = wc * 16 + q * 4 + e;
