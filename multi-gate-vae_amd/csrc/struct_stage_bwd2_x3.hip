@@ -39,7 +39,8 @@ struct B2 {
     static constexpr int o_idx = o_part + kTileRows * 4 * 16;
     static constexpr int IDX_BYTES = 2 * kIdxStride * 4;
     static constexpr int o_xe = o_idx + IDX_BYTES;            // xe_hi, xe_lo [64][XLD]
-    static constexpr int bytes = o_xe + 2 * kTileRows * XLD * 2;
+    static constexpr int o_lnacc = o_xe + 2 * kTileRows * XLD * 2;    // per-wave LayerNorm affine gradient sums [8 waves][2][16 columns]
+    static constexpr int bytes = o_lnacc + kNW * 2 * 16 * 4;
     static_assert(bytes <= 160 * 1024, "LDS budget");
     // per-workgroup gradient slab (floats): [8 waves][14 float4 slots][64 lanes] then dlnw[64], dlnb[64]
     static constexpr int SLOTS = 14;                          // 12 weight-gradient tiles, 2 bias-type tiles
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
     int* idx_base = reinterpret_cast<int*>(smem_raw + B2::o_idx);
     __bf16* xe_hi = reinterpret_cast<__bf16*>(smem_raw + B2::o_xe);
     __bf16* xe_lo = xe_hi + kTileRows * XLD;
+    float* s_lnacc = reinterpret_cast<float*>(smem_raw + B2::o_lnacc);
 
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wc = w & 3, m = w >> 2;     // wave-uniform: scalar registers
@@ -105,14 +107,14 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
     // ---- persistent accumulators
     f32x4 gW[3][4];                         // 2x2 block of this wave's matrix, per gate (wgrad_blk_x3)
     f32x4 gX[2];                            // bias-type gradients of planes p = m (pp 0) and 2 + m (pp 1), gate-column tile wc
-    float slw[4], slb[4];                   // LayerNorm affine gradients of columns c0..c0+3 over this lane's nodes
+    // LayerNorm affine gradients: summed over the 16 nodes of a lane group in registers, then added by one lane to this wave's
+    // own LDS slots (program order: deterministic); 8 VGPRs less to keep alive across the whole kernel
+    for (int i = tid; i < kNW * 2 * 16; i += kThreadsX3) s_lnacc[i] = 0.f;
 #pragma unroll
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int t = 0; t < 4; ++t) gW[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     gX[0] = gX[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { slw[e] = 0.f; slb[e] = 0.f; }
 
     // (static priority for the second-dispatched half, waves 4-7, only swaps which half waits at the barriers: measured zero-sum)
     const TileSeq seq = tile_seq(ntiles, a.xcd);
@@ -287,11 +289,17 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                 const float4 gm = ld4(sv.lnw + c0);
                 const float gm_[4] = {gm.x, gm.y, gm.z, gm.w};
                 const float shift = mw[il] - mean;
+                float lw_[4], lb_[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xhat = (vd[il][e] + shift) * rstd;
-                    slw[e] += dy_[e] * xhat; slb[e] += dy_[e];
+                    lw_[e] = group_sum<16>(dy_[e] * xhat); lb_[e] = group_sum<16>(dy_[e]);
                     dh[e] = rstd * (dy_[e] * gm_[e] - c1 - xhat * c2);
+                }
+                if (r == 0) {
+                    float* acc = s_lnacc + w * 32 + 4 * q;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[e] += lw_[e]; acc[16 + e] += lb_[e]; }
                 }
             } else {
 #pragma unroll
@@ -330,15 +338,6 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             LANE_IDS
             const __bf16* x_hi = m ? hin_hi : agg_hi;
             const __bf16* x_lo = m ? hin_lo : agg_lo;
-            if (need_dgrad) {
-                if (m == 0) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) dgo[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                } else {
-                    dgo[0] = s_dhz[(wc * 2 + 0) * 64 + lane]; dgo[1] = s_dhz[(wc * 2 + 1) * 64 + lane];
-                    dgo[2] = dhz[0]; dgo[3] = dhz[1];
-                }
-            }
             // Weight gradients of all three gates in ONE pass over the tile's two 32-row k-steps: the transposed fragments of the
             // wave's two input-column tiles (and of the [deg, onehot, 1] columns) are read once per k-step and serve every gate;
             // the bias-type tile (gX) reuses the gate-gradient fragment the 2x2 block loads anyway (its row tile wc is it0 + (wc & 1),
@@ -372,6 +371,14 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             }
             STAMP(8);
             if (need_dgrad) {
+                // seeds of the accumulators (after the weight gradients: 16 registers less to carry through them)
+                if (m == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dgo[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    dgo[0] = s_dhz[(wc * 2 + 0) * 64 + lane]; dgo[1] = s_dhz[(wc * 2 + 1) * 64 + lane];
+                    dgo[2] = dhz[0]; dgo[3] = dhz[1];
+                }
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     if (half == 1) {
@@ -437,19 +444,11 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
         for (int t = 0; t < 4; ++t) sw[(g * 4 + t) * 64] = gW[g][t];
     sw[12 * 64] = gX[0];
     sw[13 * 64] = gX[1];
-    // LayerNorm affine gradients: 16 nodes per lane group, then the two row halves (m) through LDS in a fixed order
-    float* s_ln = reinterpret_cast<float*>(s_part);
+    // LayerNorm affine gradients: the two row halves (m) in a fixed order
     __syncthreads();
-    float lw_[4], lb_[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        lw_[e] = group_sum<16>(slw[e]); lb_[e] = group_sum<16>(slb[e]);
-        if (m == 1 && r == 0) { s_ln[c0 + e] = lw_[e]; s_ln[H + c0 + e] = lb_[e]; }
-    }
-    __syncthreads();
-    if (m == 0 && r == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { slab[B2::SLAB_W + c0 + e] = lw_[e] + s_ln[c0 + e]; slab[B2::SLAB_W + H + c0 + e] = lb_[e] + s_ln[H + c0 + e]; }
+    if (tid < 2 * H) {
+        const int which = tid >> 6, c = tid & 63, wcc = c >> 4, cc = c & 15;
+        slab[B2::SLAB_W + which * H + c] = s_lnacc[wcc * 32 + which * 16 + cc] + s_lnacc[(4 + wcc) * 32 + which * 16 + cc];
     }
 }
 
