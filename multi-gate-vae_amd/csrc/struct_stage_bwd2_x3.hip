@@ -13,7 +13,7 @@
 //   * the two matrices' pre-activations meet through a lane-linear LDS exchange (each wave hands the partner the two
 //     row tiles whose epilogue the partner runs): 48 KB per tile, conflict-free 16-byte accesses.
 //   * all four gate-gradient planes (r, z, n, n*r; hi + lo) are resident at once: one dgrad + wgrad phase per tile,
-//     six workgroup barriers per tile (was twelve).
+//     five workgroup barriers per tile (was twelve), one of them behind the row gather; outputs leave straight from the accumulators.
 //   * parameter gradients leave through per-workgroup slabs and a fixed-order reduction kernel: no float atomics,
 //     bit-identical from run to run.
 #include "struct_stage_x3_common.h"
@@ -151,6 +151,9 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             float deg[2];
             int cls[2];
             tile_rows<H, 2, true>(a, base, grp, 32, lr, idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).idx, *idx_lds(idx_base, b).dmax(), acc, own, dy, deg, cls);
+            // (0) the previous tile's P4 (last reader of the planes and of xe) is over in every wave; placed here, behind the
+            //     gather, it waits where the waves wait for memory anyway
+            __syncthreads();
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int row = grp + rr * 32;
@@ -328,8 +331,9 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             st_bf4(dst + 6 * PE, hi); st_bf4(dst + 7 * PE, lo);
             if (m == 0) s_dhz[(wc * 2 + il) * 64 + lane] = dhz[il];
         }
+        idx_commit<kThreadsX3>(idx_lds(idx_base, b ^ 1).idx, ri);          // next tile's indices (requested when P1 began)
         STAMP(6);
-        __syncthreads();                                    // (4) gate-gradient planes, dh*z hand-off
+        __syncthreads();                                    // (4) gate-gradient planes, dh*z hand-off, next tile's indices
         STAMP(7);
         // ---- P4. weight gradients and dgrad, interleaved in two halves: each half's six dgrad fragments leave L2 in front of
         //      weight-gradient MFMAs that cover the latency (12 KB per wave and tile; 24 VGPRs at a time)
@@ -402,30 +406,16 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             }
         }
         STAMP(9);
-        __syncthreads();                                    // (5) planes are dead: region C becomes the two output tiles
-        STAMP(10);
-        {
-        LANE_IDS
-        if (need_dgrad) {
-            float* so = m ? s_out_dir : s_out_agg;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(so + (i * 16 + r) * LDF + c0) = dgo[i];
-        }
-        }
-        idx_commit<kThreadsX3>(idx_lds(idx_base, b ^ 1).idx, ri);
-        STAMP(11);
-        __syncthreads();                                    // (6) output tiles, next tile's indices
-        STAMP(12);
+        // ---- outputs straight from the accumulators: lane (r, q) holds 16 contiguous bytes of row 16 i + r; the four column waves
+        //      complete each 256-byte row within the same phase and L2 merges the 64-byte pieces.  No staging tile, no barrier:
+        //      the next row phase writes planes / dY / xe / deg,cls (dead since (4)), region C is rewritten after its barrier (1).
         if (need_dgrad) {
             LANE_IDS
+            float* go = m ? a.g_direct_out : a.g_agg_out;
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const int row = grp + rr * 32;
-                const int64_t node = base + row;
-                if (node < a.N) {
-                    st4(a.g_agg_out + node * H + 4 * lr, ld4(s_out_agg + row * LDF + 4 * lr));
-                    st4(a.g_direct_out + node * H + 4 * lr, ld4(s_out_dir + row * LDF + 4 * lr));
-                }
+            for (int i = 0; i < 4; ++i) {
+                const int64_t node = base + i * 16 + r;
+                if (node < a.N) *reinterpret_cast<f32x4*>(go + node * H + c0) = dgo[i];
             }
         }
         STAMP(13);

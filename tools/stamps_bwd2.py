@@ -12,8 +12,8 @@ import torch  # noqa: E402
 from deepgate import ops, synthetic as syn  # noqa: E402
 from deepgate.graph_plan import GraphPlan  # noqa: E402
 
-PH = ['P0 rows', 'bar1', 'P1 recompute+exchange', 'bar2', 'P2 gru fwd + ln partials', 'bar3', 'P3 ln/gru bwd + planes', 'bar4',
-      'P4a wgrad', 'P4b dgrad', 'bar5', 'P5 staging+idx commit', 'bar6', 'P6 stores']
+PH = ['P0 rows (+ barrier 0 behind the gather)', 'bar1', 'P1 recompute+exchange', 'bar2', 'P2 gru fwd + ln partials', 'bar3',
+      'P3 ln/gru bwd + planes', 'bar4', 'P4a wgrad', 'P4b dgrad', '(unused)', '(unused)', '(unused)', 'P5 output stores']
 
 
 def main():
