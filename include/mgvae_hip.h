@@ -247,6 +247,36 @@ int mgv_l1_loss_bwd(int64_t n, const float* x, const float* target, const float*
 int mgv_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr,
                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, int64_t step, void* stream);
 
+/* ---- on-device batch builder: what the reference recomputes in Python inside every forward —
+ * torch.stack([ei[1], ei[0]]) (digae_layer.py:264), the per-level boolean masks (dg_ae_model_aig.py:72-75), the per-node edge
+ * scans of `subgraph` (utils/dag_utils.py:91-105) — and at load time the levelisation rounds of top_sort
+ * (utils/dag_utils.py:10-37, via return_order_info :80-88).  All index arrays int32; results equal a STABLE sort of the edges by
+ * destination / source and of the nodes by (level, slot).  `status` / `done` / `maxlevel` are small DEVICE words written
+ * asynchronously (0 = fine): the caller reads them once, after the calls it batches. */
+int mgv_scan_exclusive_i32(int64_t n, const int32_t* in, int32_t* out, int32_t* scratch, void* stream);   /* out[n] = total; scratch: n/2048 + 2 */
+int mgv_plan_csr_scratch_ints(int64_t N, int64_t E);                                                  /* a size, not a status */
+int mgv_plan_csr(int64_t N, int64_t E, const int64_t* src, const int64_t* dst, int32_t* in_ptr, int32_t* in_src, int32_t* in_dst,
+                 int32_t* out_ptr, int32_t* out_dst, int32_t* out_slot, int32_t* scratch, int64_t scratch_ints, int32_t* status,
+                 void* stream);
+/* ASAP levels by frontier relaxation over the out-CSR; `rounds` level steps are enqueued; done[0] == N afterwards iff complete.
+ * scratch: 3 N + rounds + 2 ints */
+int mgv_plan_levels(int64_t N, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_dst, int32_t* level, int rounds,
+                    int32_t* scratch, int64_t scratch_ints, int32_t* done, void* stream);
+/* gate id -> aggregator slot (HOST table of 256 bytes, 255 = none), levels to int32, sort key level*T+slot (-1: never updated) */
+int mgv_plan_keys(int64_t N, int T, const float* gate, const int64_t* level64, const uint8_t* slot_of_gate_host256, uint8_t* gslot,
+                  int32_t* level32, int32_t* key, int32_t* maxlevel, void* stream);
+int mgv_plan_check_levels(int64_t E, const int32_t* in_src, const int32_t* in_dst, const uint8_t* gslot, const int32_t* level, int32_t* err,
+                          void* stream);
+int mgv_count_sort_scratch_ints(int64_t n, int K);                                                    /* a size, not a status */
+int mgv_count_sort_i32(int64_t n, const int32_t* key, int K, int32_t* order, int32_t* key_start, int32_t* scratch, int64_t scratch_ints,
+                       void* stream);
+int mgv_plan_tile_counts(int K, const int32_t* key_start, int32_t* ntile, int32_t* tile_first, int32_t* scan_scratch, void* stream);
+int mgv_plan_tiles(int K, int T, int L, int64_t n_active, const int32_t* key_start, const int32_t* tile_first, const int32_t* order,
+                   const int32_t* in_ptr, const int32_t* out_ptr, int32_t* tile_start, int32_t* tile_count, int32_t* tile_slot,
+                   int32_t* order_span, int32_t* level_tile_ptr, void* stream);
+int mgv_plan_pairs(int64_t N, const int32_t* in_ptr, const uint8_t* xcls, int32_t* present, int32_t* rank, int32_t* scan_scratch, int32_t* cid,
+                   int32_t* cls_deg, uint8_t* cls_x, int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,488 @@
+// On-device batch builder: edge list -> in/out CSR, ASAP levels, (level, gate-type) buckets and
+// 64-node tiles, as HIP kernels.  Replaces, on the GPU, the torch sorts / scans of deepgate/graph_plan.py and the host
+// frontier loop of deepgate/parser.py::forward_levels; results are IDENTICAL to those (same stable orders), which the
+// GPU tests assert array by array.  What the reference does instead: `torch.stack([ei[1], ei[0]])` per stage
+// (digae_layer.py:264), boolean level / gate masks per level (dg_ae_model_aig.py:72-75), per-node edge scans
+// (utils/dag_utils.py:91-105) and the O(levels x E) numpy rounds of top_sort (utils/dag_utils.py:10-37).
+//
+// Building blocks (all int32, HBM-bound integer work; int atomics run at L2 speed, unlike float atomics):
+//   * exclusive scan: 2,048 items per block (local scan + block total), one block over the totals, add-back;
+//   * CSR: degree histogram (atomicAdd), scan, cursor fill of EDGE IDS, then every node sorts its (short) list of edge ids
+//     ascending — the result is the stable order of a stable sort by destination / source — and a gather pass;
+//   * stable counting sort by a small key (level * T + slot <= a few thousand): per-block LDS histograms laid out
+//     [key][block], ONE flat exclusive scan gives every (key, block) its base, blocks place their nodes in wave order;
+//   * ASAP levels: frontier relaxation over the out-CSR (Kahn), one launch per level, frontier sizes stay on the device.
+#include "mgv_common.h"
+#include "../../include/mgvae_hip.h"
+
+namespace mgv {
+
+constexpr int kScanItems = 2048;           // items per scan block (256 threads x 8)
+constexpr int kSortBlock = 1024;           // items per counting-sort block
+constexpr int kMaxKeys = 8192;             // LDS histogram bins of the counting sort
+
+// ------------------------------------------------------------------------------------------------ scan
+__global__ __launch_bounds__(256) void k_scan_block(int64_t n, const int32_t* in, int32_t* out, int32_t* sums) {
+    __shared__ int s_w[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanItems + threadIdx.x * 8;
+    int v[8], t = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = base + k < n ? in[base + k] : 0; t += v[k]; }
+    // exclusive prefix of t over the 256 threads
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d, 64); if (lane >= d) inc += u; }
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < w; ++k) woff += s_w[k];
+    int run = woff + inc - t;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+    if (threadIdx.x == 255) sums[blockIdx.x] = run;
+}
+
+// one block: exclusive scan of the block totals in place, grand total appended at sums[nb]
+__global__ __launch_bounds__(1024) void k_scan_sums(int nb, int32_t* sums) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        const int i = b0 + threadIdx.x;
+        const int t = i < nb ? sums[i] : 0;
+        int inc = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d, 64); if (lane >= d) inc += u; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int woff = s_carry;
+        for (int k = 0; k < w; ++k) woff += s_w[k];
+        if (i < nb) sums[i] = woff + inc - t;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[nb] = s_carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(int64_t n, int32_t* out, const int32_t* sums, int nb) {
+    const int off = sums[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * kScanItems + threadIdx.x * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (base + k < n) out[base + k] += off;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[nb];       // total behind the last element
+}
+
+// out[0..n] = exclusive prefix sums of in[0..n), out[n] = total; scratch >= ceil(n / 2048) + 1 ints
+static int scan_exclusive(int64_t n, const int32_t* in, int32_t* out, int32_t* scratch, hipStream_t st) {
+    const int nb = (int)((n + kScanItems - 1) / kScanItems);
+    if (n == 0) { hipMemsetAsync(out, 0, sizeof(int32_t), st); MGV_LAUNCH_RET(); }
+    hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, st, n, in, out, scratch);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, nb, scratch);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, st, n, out, scratch, nb);
+    MGV_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------------ CSR
+__global__ __launch_bounds__(256) void k_csr_count(int64_t E, int64_t N, const int64_t* src, const int64_t* dst, int32_t* deg_in, int32_t* deg_out,
+                                                   int32_t* err) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+        const int64_t s = src[e], d = dst[e];
+        if (s < 0 || s >= N || d < 0 || d >= N) { *err = 1; continue; }
+        atomicAdd(deg_in + d, 1);
+        atomicAdd(deg_out + s, 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_csr_fill(int64_t E, int64_t N, const int64_t* src, const int64_t* dst, int32_t* cur_in, int32_t* cur_out,
+                                                  int32_t* eid_in, int32_t* eid_out) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+        const int64_t s = src[e], d = dst[e];
+        if (s < 0 || s >= N || d < 0 || d >= N) continue;
+        eid_in[atomicAdd(cur_in + d, 1)] = (int32_t)e;
+        eid_out[atomicAdd(cur_out + s, 1)] = (int32_t)e;
+    }
+}
+
+// every node's list of edge ids ascending (= original edge order).  Short lists in registers; long ones are handed to
+// k_sort_heavy through a list.
+constexpr int kShortList = 32;
+__global__ __launch_bounds__(256) void k_sort_lists(int64_t N, const int32_t* ptr, int32_t* eid, int32_t* heavy, int32_t* n_heavy) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int p0 = ptr[n], d = ptr[n + 1] - p0;
+    if (d <= 1) return;
+    if (d > kShortList) { heavy[atomicAdd(n_heavy, 1)] = (int32_t)n; return; }
+    int v[kShortList];
+#pragma unroll
+    for (int k = 0; k < kShortList; ++k) v[k] = k < d ? eid[p0 + k] : 0x7fffffff;
+    // odd-even transposition network on a fixed 32-entry array: no data-dependent indexing (stays in registers)
+#pragma unroll 1
+    for (int pass = 0; pass < d; ++pass) {
+#pragma unroll
+        for (int k = 0; k + 1 < kShortList; k += 2) { const int a = min(v[k], v[k + 1]), b = max(v[k], v[k + 1]); v[k] = a; v[k + 1] = b; }
+#pragma unroll
+        for (int k = 1; k + 1 < kShortList; k += 2) { const int a = min(v[k], v[k + 1]), b = max(v[k], v[k + 1]); v[k] = a; v[k + 1] = b; }
+    }
+#pragma unroll
+    for (int k = 0; k < kShortList; ++k) if (k < d) eid[p0 + k] = v[k];
+}
+
+// one block per long list: bitonic sort in LDS up to 4,096 entries, rank sort (O(d^2 / 1024), rare) beyond
+constexpr int kHeavyLds = 4096;
+__global__ __launch_bounds__(1024) void k_sort_heavy(const int32_t* heavy, const int32_t* n_heavy, const int32_t* ptr, int32_t* eid, int32_t* tmp) {
+    __shared__ int s_v[kHeavyLds];
+    for (int h = blockIdx.x; h < *n_heavy; h += gridDim.x) {
+        const int n = heavy[h];
+        const int p0 = ptr[n], d = ptr[n + 1] - p0;
+        if (d <= kHeavyLds) {
+            int m = 1;
+            while (m < d) m <<= 1;
+            for (int i = threadIdx.x; i < m; i += 1024) s_v[i] = i < d ? eid[p0 + i] : 0x7fffffff;
+            __syncthreads();
+            for (int k = 2; k <= m; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = threadIdx.x; i < m; i += 1024) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const int a = s_v[i], b = s_v[l];
+                            const bool up = (i & k) == 0;
+                            if ((a > b) == up) { s_v[i] = b; s_v[l] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = threadIdx.x; i < d; i += 1024) eid[p0 + i] = s_v[i];
+            __syncthreads();
+        } else {
+            for (int i = threadIdx.x; i < d; i += 1024) {          // edge ids are distinct: rank = number of smaller ids
+                const int a = eid[p0 + i];
+                int r = 0;
+                for (int j = 0; j < d; ++j) r += eid[p0 + j] < a;
+                tmp[p0 + r] = a;
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < d; i += 1024) eid[p0 + i] = tmp[p0 + i];
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_csr_finish_in(int64_t E, const int64_t* src, const int64_t* dst, const int32_t* eid_in, int32_t* in_src,
+                                                       int32_t* in_dst, int32_t* pos_in) {
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < E; s += (int64_t)gridDim.x * 256) {
+        const int e = eid_in[s];
+        in_src[s] = (int32_t)src[e];
+        in_dst[s] = (int32_t)dst[e];
+        pos_in[e] = (int32_t)s;
+    }
+}
+__global__ __launch_bounds__(256) void k_csr_finish_out(int64_t E, const int64_t* dst, const int32_t* eid_out, const int32_t* pos_in, int32_t* out_dst,
+                                                        int32_t* out_slot) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < E; t += (int64_t)gridDim.x * 256) {
+        const int e = eid_out[t];
+        out_dst[t] = (int32_t)dst[e];
+        out_slot[t] = pos_in[e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ levels (Kahn over the out-CSR)
+__global__ __launch_bounds__(256) void k_level_seed(int64_t N, const int32_t* in_ptr, int32_t* pending, int32_t* level, int32_t* frontier, int32_t* fcount) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int d = in_ptr[n + 1] - in_ptr[n];
+    pending[n] = d;
+    level[n] = 0;
+    if (d == 0) frontier[atomicAdd(fcount, 1)] = (int32_t)n;
+}
+// one level: children of the frontier lose one pending parent per edge; those that reach zero form the next frontier
+__global__ __launch_bounds__(256) void k_level_step(const int32_t* frontier, const int32_t* fcount, int32_t* next, int32_t* ncount, const int32_t* out_ptr,
+                                                    const int32_t* out_dst, int32_t* pending, int32_t* level, int cur, int32_t* done) {
+    const int nf = *fcount;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nf; i += gridDim.x * 256) {
+        const int n = frontier[i];
+        for (int e = out_ptr[n]; e < out_ptr[n + 1]; ++e) {
+            const int c = out_dst[e];
+            if (atomicSub(pending + c, 1) == 1) { level[c] = cur + 1; next[atomicAdd(ncount, 1)] = c; }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(done, nf);
+}
+
+// ------------------------------------------------------------------------------------------------ buckets
+struct SlotTable { uint8_t slot[256]; };
+
+__global__ __launch_bounds__(256) void k_bucket_keys(int64_t N, int T, const float* gate, const int64_t* level64, SlotTable tab, uint8_t* gslot,
+                                                     int32_t* level32, int32_t* key, int32_t* maxlevel) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    int g = (int)gate[n];
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    const int s = tab.slot[g];
+    const int64_t lv = level64[n];
+    const bool active = lv >= 1 && s != 255;
+    gslot[n] = active ? (uint8_t)s : (uint8_t)255;
+    level32[n] = (int32_t)lv;
+    key[n] = active ? (int32_t)(lv * T + s) : -1;
+    atomicMax(maxlevel, (int32_t)lv);
+}
+
+// every source of an updated node must sit on a strictly lower level
+__global__ __launch_bounds__(256) void k_check_levels(int64_t E, const int32_t* in_src, const int32_t* in_dst, const uint8_t* gslot, const int32_t* level,
+                                                      int32_t* err) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+        const int d = in_dst[e], s = in_src[e];
+        if (gslot[d] != 255 && level[s] >= level[d]) *err = 2;
+    }
+}
+
+// counting sort, step 1: cnt[key * B + block] = items of `key` in the block (items with key < 0 are skipped)
+__global__ __launch_bounds__(kSortBlock) void k_sort_hist(int64_t n, const int32_t* key, int K, int B, int32_t* cnt) {
+    __shared__ int s_h[kMaxKeys];
+    for (int i = threadIdx.x; i < K; i += kSortBlock) s_h[i] = 0;
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kSortBlock + threadIdx.x;
+    const int k = i < n ? key[i] : -1;
+    if (k >= 0) atomicAdd(s_h + k, 1);
+    __syncthreads();
+    for (int j = threadIdx.x; j < K; j += kSortBlock) if (s_h[j]) cnt[(int64_t)j * B + blockIdx.x] = s_h[j];
+}
+// step 3 (after the flat scan of cnt into base): place items; within a block wave by wave, within a wave by lane: stable
+__global__ __launch_bounds__(kSortBlock) void k_sort_place(int64_t n, const int32_t* key, int K, int B, const int32_t* base, int32_t* order) {
+    __shared__ int s_c[kMaxKeys];
+    for (int i = threadIdx.x; i < K; i += kSortBlock) s_c[i] = base[(int64_t)i * B + blockIdx.x];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * kSortBlock + threadIdx.x;
+    const int k = i < n ? key[i] : -1;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int turn = 0; turn < kSortBlock / 64; ++turn) {
+        if (w == turn) {
+            unsigned long long todo = __ballot(k >= 0);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int kk = __shfl(k, leader, 64);
+                const unsigned long long same = __ballot(k == kk) & todo;
+                if (k == kk) {
+                    const int r = s_c[kk] + __popcll(same & ((1ull << lane) - 1ull));
+                    order[r] = (int32_t)i;
+                }
+                if (lane == leader) s_c[kk] += __popcll(same);
+                todo &= ~same;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_key_starts(int K, int B, const int32_t* base, int32_t* key_start) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k <= K) key_start[k] = base[(int64_t)k * B];      // k = K: the total behind the last (key, block) cell
+}
+__global__ __launch_bounds__(256) void k_key_counts(int K, int B, const int32_t* base, int32_t* ntile) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int c = base[(int64_t)(k + 1) * B] - base[(int64_t)k * B];       // base has K*B + 1 entries
+    ntile[k] = (c + kTileRows - 1) / kTileRows;
+}
+__global__ __launch_bounds__(256) void k_tiles_fill(int K, int B, int T, const int32_t* base, const int32_t* tile_first, int32_t* tile_start,
+                                                    int32_t* tile_count, int32_t* tile_slot) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const int s0 = base[(int64_t)k * B], c = base[(int64_t)(k + 1) * B] - s0;
+    for (int t = 0, f = tile_first[k]; t * kTileRows < c; ++t) {
+        tile_start[f + t] = s0 + t * kTileRows;
+        tile_count[f + t] = min(kTileRows, c - t * kTileRows);
+        tile_slot[f + t] = k % T;
+    }
+}
+__global__ __launch_bounds__(256) void k_order_span(int64_t n_active, const int32_t* order, const int32_t* in_ptr, const int32_t* out_ptr, int4* span) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_active) return;
+    const int n = order[i];
+    span[i] = make_int4(in_ptr[n], in_ptr[n + 1], out_ptr[n], out_ptr[n + 1]);
+}
+__global__ __launch_bounds__(256) void k_level_tile_ptr(int L, int T, const int32_t* tile_first, int32_t* ltp) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l <= L) ltp[l] = tile_first[min(l * T, L * T)];
+}
+
+// (degree, class) pairs of the forward CSR -> dense class ids (first half round of an encoder, digae_layer.py:260)
+__global__ __launch_bounds__(256) void k_pair_mark(int64_t N, const int32_t* in_ptr, const uint8_t* xcls, int32_t* present, int32_t* err) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int d = in_ptr[n + 1] - in_ptr[n];
+    if (d > 255) { *err = 3; return; }
+    present[d * 256 + xcls[n]] = 1;
+}
+__global__ __launch_bounds__(256) void k_pair_ids(int64_t N, const int32_t* in_ptr, const uint8_t* xcls, const int32_t* rank, int32_t* cid) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int d = min(in_ptr[n + 1] - in_ptr[n], 255);
+    cid[n] = rank[d * 256 + xcls[n]];
+}
+__global__ __launch_bounds__(256) void k_pair_table(const int32_t* present, const int32_t* rank, int32_t* cls_deg, uint8_t* cls_x) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < 65536 && present[p]) { cls_deg[rank[p]] = p >> 8; cls_x[rank[p]] = (uint8_t)(p & 255); }
+}
+
+static inline int blocks_for(int64_t n, int per = 256, int cap = 256 * 64) { const int64_t b = (n + per - 1) / per; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
+
+}  // namespace mgv
+
+using namespace mgv;
+
+extern "C" int mgv_scan_exclusive_i32(int64_t n, const int32_t* in, int32_t* out, int32_t* scratch, void* stream) {
+    MGV_CHECK_ARG(n >= 0 && out && scratch && (n == 0 || in));
+    return scan_exclusive(n, in, out, scratch, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mgv_plan_csr_scratch_ints(int64_t N, int64_t E) { return (int)(2 * N + 4 * E + (N + E) / kScanItems + 64); }
+
+/* scratch (int32): cur_in[N] cur_out[N] eid_in[E] eid_out[E] pos_in[E] tmp[E] scan[...] flags[8]; flags are returned in status[0..1]
+ * (status[0]: 1 = node id out of range; device memory, 2 ints, written asynchronously) */
+extern "C" int mgv_plan_csr(int64_t N, int64_t E, const int64_t* src, const int64_t* dst, int32_t* in_ptr, int32_t* in_src, int32_t* in_dst,
+                            int32_t* out_ptr, int32_t* out_dst, int32_t* out_slot, int32_t* scratch, int64_t scratch_ints, int32_t* status,
+                            void* stream) {
+    MGV_CHECK_ARG(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31) && in_ptr && out_ptr && scratch && status);
+    MGV_CHECK_ARG(scratch_ints >= mgv_plan_csr_scratch_ints(N, E));
+    MGV_CHECK_ARG(E == 0 || (src && dst && in_src && in_dst && out_dst && out_slot));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t* cur_in = scratch;
+    int32_t* cur_out = cur_in + N;
+    int32_t* eid_in = cur_out + N;
+    int32_t* eid_out = eid_in + E;
+    int32_t* pos_in = eid_out + E;
+    int32_t* tmp = pos_in + E;
+    int32_t* scan = tmp + E;
+    hipMemsetAsync(cur_in, 0, 2 * N * sizeof(int32_t), st);
+    hipMemsetAsync(status, 0, 2 * sizeof(int32_t), st);
+    if (E > 0) hipLaunchKernelGGL(k_csr_count, dim3(blocks_for(E)), dim3(256), 0, st, E, N, src, dst, cur_in, cur_out, status);
+    int rc = scan_exclusive(N, cur_in, in_ptr, scan, st);
+    if (rc != MGV_OK) return rc;
+    rc = scan_exclusive(N, cur_out, out_ptr, scan, st);
+    if (rc != MGV_OK) return rc;
+    if (E == 0) return MGV_OK;
+    hipMemcpyAsync(cur_in, in_ptr, N * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(cur_out, out_ptr, N * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    hipLaunchKernelGGL(k_csr_fill, dim3(blocks_for(E)), dim3(256), 0, st, E, N, src, dst, cur_in, cur_out, eid_in, eid_out);
+    // per-node sorts; the heavy list reuses the cursor arrays (dead after the fill): list at cur_in[0..N), counter in status[1]
+    for (int dir = 0; dir < 2; ++dir) {
+        int32_t* eid = dir ? eid_out : eid_in;
+        const int32_t* ptr = dir ? out_ptr : in_ptr;
+        int32_t* heavy = dir ? cur_out : cur_in;
+        int32_t* n_heavy = scan + dir;                      // two counters in the (now idle) scan scratch
+        hipMemsetAsync(n_heavy, 0, sizeof(int32_t), st);
+        hipLaunchKernelGGL(k_sort_lists, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, ptr, eid, heavy, n_heavy);
+        hipLaunchKernelGGL(k_sort_heavy, dim3(256), dim3(1024), 0, st, heavy, n_heavy, ptr, eid, tmp);
+    }
+    hipLaunchKernelGGL(k_csr_finish_in, dim3(blocks_for(E)), dim3(256), 0, st, E, src, dst, eid_in, in_src, in_dst, pos_in);
+    hipLaunchKernelGGL(k_csr_finish_out, dim3(blocks_for(E)), dim3(256), 0, st, E, dst, eid_out, pos_in, out_dst, out_slot);
+    MGV_LAUNCH_RET();
+}
+
+/* ASAP levels of a DAG from its CSRs (utils/dag_utils.py:10-37 semantics: the round in which all parents have been evaluated).
+ * `rounds` launches are enqueued without a host round trip; done[0] accumulates the number of nodes levelised: the caller
+ * checks done[0] == N afterwards (fewer: more rounds needed, or a cycle).  scratch: pending[N], frontier[2][N], counts[rounds + 2]. */
+extern "C" int mgv_plan_levels(int64_t N, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_dst, int32_t* level, int rounds,
+                               int32_t* scratch, int64_t scratch_ints, int32_t* done, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && rounds >= 1 && in_ptr && out_ptr && level && scratch && done && scratch_ints >= 3 * N + rounds + 2);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (N == 0) return MGV_OK;
+    int32_t* pending = scratch;
+    int32_t* fr[2] = {pending + N, pending + 2 * N};
+    int32_t* counts = pending + 3 * N;                      // one counter per round (round r fills counts[r + 1])
+    hipMemsetAsync(counts, 0, (rounds + 2) * sizeof(int32_t), st);
+    hipMemsetAsync(done, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL(k_level_seed, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, in_ptr, pending, level, fr[0], counts);
+    for (int r = 0; r < rounds; ++r)
+        hipLaunchKernelGGL(k_level_step, dim3(512), dim3(256), 0, st, fr[r & 1], counts + r, fr[(r + 1) & 1], counts + r + 1, out_ptr, out_dst, pending,
+                           level, r, done);
+    MGV_LAUNCH_RET();
+}
+
+/* gate ids -> aggregator slots, int32 levels, sort keys; maxlevel[0] receives the largest level (device int, zeroed here) */
+extern "C" int mgv_plan_keys(int64_t N, int T, const float* gate, const int64_t* level64, const uint8_t* slot_of_gate_host256, uint8_t* gslot,
+                             int32_t* level32, int32_t* key, int32_t* maxlevel, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && T >= 1 && T <= 255 && slot_of_gate_host256 && maxlevel && (N == 0 || (gate && level64 && gslot && level32 && key)));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipMemsetAsync(maxlevel, 0, sizeof(int32_t), st);
+    if (N == 0) return MGV_OK;
+    SlotTable tab;
+    for (int i = 0; i < 256; ++i) tab.slot[i] = slot_of_gate_host256[i];
+    hipLaunchKernelGGL(k_bucket_keys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, T, gate, level64, tab, gslot, level32, key, maxlevel);
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_plan_check_levels(int64_t E, const int32_t* in_src, const int32_t* in_dst, const uint8_t* gslot, const int32_t* level, int32_t* err,
+                                     void* stream) {
+    MGV_CHECK_ARG(E >= 0 && err && (E == 0 || (in_src && in_dst && gslot && level)));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipMemsetAsync(err, 0, sizeof(int32_t), st);
+    if (E > 0) hipLaunchKernelGGL(k_check_levels, dim3(blocks_for(E)), dim3(256), 0, st, E, in_src, in_dst, gslot, level, err);
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_count_sort_scratch_ints(int64_t n, int K) {
+    const int64_t B = (n + kSortBlock - 1) / kSortBlock;
+    const int64_t m = (int64_t)K * (B < 1 ? 1 : B) + 1;
+    return (int)(2 * m + m / kScanItems + 64);
+}
+/* Stable counting sort of the items 0..n-1 by key[i] in [0, K) (key < 0: item dropped): order[] = item ids by (key, id),
+ * key_start[K + 1] = first position of each key.  K <= 8192. */
+extern "C" int mgv_count_sort_i32(int64_t n, const int32_t* key, int K, int32_t* order, int32_t* key_start, int32_t* scratch, int64_t scratch_ints,
+                                  void* stream) {
+    MGV_CHECK_ARG(n >= 0 && K >= 1 && K <= kMaxKeys && key_start && scratch && scratch_ints >= mgv_count_sort_scratch_ints(n, K));
+    MGV_CHECK_ARG(n == 0 || (key && order));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int B = (int)((n + kSortBlock - 1) / kSortBlock) < 1 ? 1 : (int)((n + kSortBlock - 1) / kSortBlock);
+    const int64_t m = (int64_t)K * B;
+    int32_t* cnt = scratch;
+    int32_t* base = cnt + m + 1;
+    int32_t* scan = base + m + 1;
+    hipMemsetAsync(cnt, 0, m * sizeof(int32_t), st);
+    if (n > 0) hipLaunchKernelGGL(k_sort_hist, dim3(B), dim3(kSortBlock), 0, st, n, key, K, B, cnt);
+    int rc = scan_exclusive(m, cnt, base, scan, st);
+    if (rc != MGV_OK) return rc;
+    if (n > 0) hipLaunchKernelGGL(k_sort_place, dim3(B), dim3(kSortBlock), 0, st, n, key, K, B, base, order);
+    hipLaunchKernelGGL(k_key_starts, dim3((K + 256) / 256), dim3(256), 0, st, K, B, base, key_start);
+    MGV_LAUNCH_RET();
+}
+
+/* tiles of <= 64 consecutive entries of one key each, from key_start[K + 1] (K = levels * T): ntile/tile_first are scratch of
+ * K + 1 ints (+ scan scratch); tile_first[K] = number of tiles (device) */
+extern "C" int mgv_plan_tile_counts(int K, const int32_t* key_start, int32_t* ntile, int32_t* tile_first, int32_t* scan_scratch, void* stream) {
+    MGV_CHECK_ARG(K >= 1 && key_start && ntile && tile_first && scan_scratch);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_key_counts, dim3((K + 255) / 256), dim3(256), 0, st, K, 1, key_start, ntile);
+    return scan_exclusive(K, ntile, tile_first, scan_scratch, st);
+}
+extern "C" int mgv_plan_tiles(int K, int T, int L, int64_t n_active, const int32_t* key_start, const int32_t* tile_first, const int32_t* order,
+                              const int32_t* in_ptr, const int32_t* out_ptr, int32_t* tile_start, int32_t* tile_count, int32_t* tile_slot,
+                              int32_t* order_span, int32_t* level_tile_ptr, void* stream) {
+    MGV_CHECK_ARG(K >= 1 && T >= 1 && L >= 1 && K == L * T && key_start && tile_first && level_tile_ptr);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_tiles_fill, dim3((K + 255) / 256), dim3(256), 0, st, K, 1, T, key_start, tile_first, tile_start, tile_count, tile_slot);
+    if (n_active > 0) hipLaunchKernelGGL(k_order_span, dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, st, n_active, order, in_ptr, out_ptr,
+                                         reinterpret_cast<int4*>(order_span));
+    hipLaunchKernelGGL(k_level_tile_ptr, dim3((L + 256) / 256), dim3(256), 0, st, L, T, tile_first, level_tile_ptr);
+    MGV_LAUNCH_RET();
+}
+
+/* (in-degree, feature class) pairs -> class ids: present/rank are scratch of 65,537 ints each (+ scan scratch of 64); n_cls = rank[65536]
+ * (device); status[0] = 3 when a degree exceeds 255 (caller falls back to per-node launches) */
+extern "C" int mgv_plan_pairs(int64_t N, const int32_t* in_ptr, const uint8_t* xcls, int32_t* present, int32_t* rank, int32_t* scan_scratch, int32_t* cid,
+                              int32_t* cls_deg, uint8_t* cls_x, int32_t* status, void* stream) {
+    MGV_CHECK_ARG(N >= 1 && in_ptr && xcls && present && rank && scan_scratch && cid && cls_deg && cls_x && status);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipMemsetAsync(present, 0, 65536 * sizeof(int32_t), st);
+    hipMemsetAsync(status, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL(k_pair_mark, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, in_ptr, xcls, present, status);
+    const int rc = scan_exclusive(65536, present, rank, scan_scratch, st);
+    if (rc != MGV_OK) return rc;
+    hipLaunchKernelGGL(k_pair_ids, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, in_ptr, xcls, rank, cid);
+    hipLaunchKernelGGL(k_pair_table, dim3(256), dim3(256), 0, st, present, rank, cls_deg, cls_x);
+    MGV_LAUNCH_RET();
+}

@@ -60,6 +60,10 @@ def plan_of(batch, gate_ids):
         plan.level_key = None
         batch._mgv_plan = plan
     if plan.level_key != key:
+        if getattr(batch, 'forward_level', None) is None:
+            # batches from a loader that skipped the host levelisation (NpzParser(levelise=False)): levels on the device
+            batch.forward_level = plan.asap_levels()
+            batch.forward_index = torch.arange(batch.x.shape[0], device=dev)
         plan.set_levels(batch.gate, batch.forward_level, list(key))
         # structural feature class = x[:, 1] as an integer (the one_hot(x[:,1]) quirk, dg_ae_model_aig.py:59)
         cls = batch.x[:, 1].to(torch.long)

@@ -4,9 +4,15 @@ Replaces, for the whole batch at once, what the reference recomputes inside ever
 `torch.stack([edge_index[1], edge_index[0]])` (digae_layer.py:264), the boolean level/gate masks and
 `forward_index[mask]` (dg_ae_model_aig.py:72-75) and the per-node edge scans of `subgraph`
 (utils/dag_utils.py:91-105, O(nodes x E) Python) — with two CSRs and a list of 64-node tiles
-bucketed by (level, gate type).  Built with torch ops on whatever device the batch lives on; it is
-batch construction, not part of the timed train step.
+bucketed by (level, gate type).  On the GPU the plan is built by the HIP kernels of csrc/plan_build.hip (degree
+histogram + scan + cursor fill + per-list sort for the CSRs, a stable counting sort by (level, slot) for the buckets:
+SURVEY.md §8f row 1); on CPU tensors (host-logic tests, and `MGV_PLAN=torch` as the GPU tests' cross-check) by the
+torch sorts / scans below.  Both give identical arrays.  It is batch construction, not part of the timed train step
+(SURVEY.md §8d).
 """
+import ctypes
+import os
+
 import torch
 
 TILE = 64
@@ -31,6 +37,11 @@ class GraphPlan:
             raise ValueError('node/edge counts must fit int32')
         src, dst = ei[0].long(), ei[1].long()
         self.N, self.E, self.device = N, E, dev
+        self.hip = dev.type == 'cuda' and os.environ.get('MGV_PLAN', 'hip') != 'torch'
+        if self.hip:
+            self._build_csr_hip(src.contiguous(), dst.contiguous())
+            self.has_levels = False
+            return
         perm_in = torch.sort(dst, stable=True).indices
         perm_out = torch.sort(src, stable=True).indices
         self.in_src = src[perm_in].to(torch.int32).contiguous()
@@ -43,6 +54,55 @@ class GraphPlan:
         self.in_dst = dst[perm_in].to(torch.int32).contiguous()   # destination of each in-CSR slot
         self.perm_in = perm_in
         self.has_levels = False
+
+    def _build_csr_hip(self, src, dst):
+        from . import _hip
+        from ._hip import ptr
+        N, E, dev = self.N, self.E, self.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.in_ptr, self.out_ptr = torch.empty(N + 1, **i32), torch.empty(N + 1, **i32)
+        self.in_src, self.in_dst = torch.empty(max(E, 1), **i32)[:E], torch.empty(max(E, 1), **i32)[:E]
+        self.out_dst, self.out_slot = torch.empty(max(E, 1), **i32)[:E], torch.empty(max(E, 1), **i32)[:E]
+        n_s = _hip.call_value('mgv_plan_csr_scratch_ints', N, E)
+        scratch = torch.empty(n_s, **i32)
+        status = torch.empty(2, **i32)
+        _hip.call('mgv_plan_csr', N, E, ptr(src), ptr(dst), ptr(self.in_ptr), ptr(self.in_src), ptr(self.in_dst), ptr(self.out_ptr),
+                  ptr(self.out_dst), ptr(self.out_slot), ptr(scratch), n_s, ptr(status))
+        self._status = status            # read together with the level checks (one host round trip per batch)
+        self._keep = (src, dst)
+
+    def asap_levels(self):
+        """ASAP level of every node (the round of utils/dag_utils.top_sort in which it is evaluated = longest path from a source),
+        by frontier relaxation over the out-CSR on the device.  Raises on a cycle.  -> int64 [N]"""
+        N, dev = self.N, self.device
+        if not self.hip:
+            from .parser import forward_levels
+            ei = torch.stack([self.in_src.long(), self.in_dst.long()]).cpu().numpy()
+            return torch.from_numpy(forward_levels(ei, N)).to(dev)
+        from . import _hip
+        from ._hip import ptr
+        self._check_status()
+        level = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)[:N]
+        if N == 0:
+            return level.long()
+        done = torch.zeros(1, dtype=torch.int32, device=dev)
+        rounds = 512
+        while True:
+            scratch = torch.empty(3 * N + rounds + 2, dtype=torch.int32, device=dev)
+            _hip.call('mgv_plan_levels', N, ptr(self.in_ptr), ptr(self.out_ptr), ptr(self.out_dst), ptr(level), rounds, ptr(scratch),
+                      scratch.numel(), ptr(done))
+            if int(done.item()) == N:
+                return level.long()
+            if rounds >= N + 1:              # more rounds than nodes cannot help: some node never lost its last pending parent
+                raise ValueError('edge_index is not a DAG (%d of %d nodes levelised)' % (int(done.item()), N))
+            rounds = min(rounds * 8, N + 1)
+
+    def _check_status(self):
+        st = getattr(self, '_status', None)
+        if st is not None:
+            self._status = None
+            if int(st[0].item()) != 0:
+                raise ValueError('edge_index holds node ids outside [0, num_nodes)')
 
     @staticmethod
     def _ptr(index, n):
@@ -66,6 +126,11 @@ class GraphPlan:
         hit = getattr(self, '_stage1', None)
         if hit is not None and hit[0] == key:
             return hit[1]
+        if self.hip and self.N > 0:
+            out = self._first_stage_classes_hip(xcls, max_classes)
+            if out is not False:
+                self._stage1 = (key, out)
+                return out
         deg = (self.in_ptr[1:] - self.in_ptr[:-1]).long()
         pair = deg * 256 + xcls.long()
         uniq, inv = torch.unique(pair, return_inverse=True)
@@ -81,9 +146,92 @@ class GraphPlan:
         self._stage1 = (key, out)
         return out
 
+    def _first_stage_classes_hip(self, xcls, max_classes):
+        from . import _hip
+        from ._hip import ptr
+        N, dev = self.N, self.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        work = torch.empty(2 * 65537 + 64, **i32)
+        cid = torch.empty(N, **i32)
+        cls_deg = torch.zeros(65536, **i32)
+        cls_x = torch.zeros(65536, dtype=torch.uint8, device=dev)
+        status = torch.empty(1, **i32)
+        xc = xcls.contiguous()
+        _hip.call('mgv_plan_pairs', N, ptr(self.in_ptr), ptr(xc), ptr(work), ptr(work[65537:]), ptr(work[2 * 65537:]), ptr(cid), ptr(cls_deg),
+                  ptr(cls_x), ptr(status))
+        C, bad = int(work[65537 + 65536].item()), int(status.item())
+        if bad:
+            return False                       # a degree above 255: the torch path handles it
+        if not 0 < C <= max_classes:
+            return None
+        d = cls_deg[:C].long()
+        p = torch.zeros(C + 1, dtype=torch.int64, device=dev)
+        p[1:] = torch.cumsum(d, 0)             # C entries: a dozen
+        idx = torch.zeros(max(int(p[-1].item()), 1), **i32)
+        return (cid, C, p.to(torch.int32).contiguous(), idx, cls_x[:C].contiguous())
+
+    def _set_levels_hip(self, gate, forward_level, gate_ids):
+        from . import _hip
+        from ._hip import ptr
+        N, E, dev, T = self.N, self.E, self.device, len(gate_ids)
+        i32 = dict(dtype=torch.int32, device=dev)
+        g = gate.reshape(-1).to(dev, torch.float32).contiguous()
+        lv = forward_level.reshape(-1).to(dev, torch.int64).contiguous()
+        if g.numel() != N or lv.numel() != N:
+            raise ValueError('gate / forward_level must have one entry per node')
+        tab = (ctypes.c_uint8 * 256)(*([NO_GATE] * 256))
+        for s_, gid in enumerate(gate_ids):
+            tab[int(gid)] = s_
+        self.gslot = torch.empty(N, dtype=torch.uint8, device=dev)
+        self.level = torch.empty(N, **i32)
+        key = torch.empty(max(N, 1), **i32)
+        flags = torch.zeros(2, **i32)                       # [max level, level-order violation]
+        _hip.call('mgv_plan_keys', N, T, ptr(g), ptr(lv), tab, ptr(self.gslot), ptr(self.level), ptr(key), ptr(flags))
+        _hip.call('mgv_plan_check_levels', E, ptr(self.in_src), ptr(self.in_dst), ptr(self.gslot), ptr(self.level), ptr(flags[1:]))
+        self._check_status()
+        maxlevel, bad = (int(v) for v in flags.tolist())    # the batch's first host round trip
+        if bad:
+            raise ValueError('forward_level is not a topological levelisation of edge_index')
+        L = maxlevel + 1 if N > 0 else 0
+        self.num_levels = L
+        K = max(L, 1) * T
+        if K > 8192:
+            return False
+        order = torch.empty(max(N, 1), **i32)
+        key_start = torch.empty(K + 1, **i32)
+        n_s = _hip.call_value('mgv_count_sort_scratch_ints', N, K)
+        scratch = torch.empty(n_s, **i32)
+        _hip.call('mgv_count_sort_i32', N, ptr(key), K, ptr(order), ptr(key_start), ptr(scratch), n_s)
+        small = torch.empty(2 * (K + 1) + K // 2048 + 64 + max(L, 1) + 1, **i32)
+        ntile, tile_first, scan_s = small[:K + 1], small[K + 1:2 * (K + 1)], small[2 * (K + 1):2 * (K + 1) + K // 2048 + 64]
+        ltp_dev = small[2 * (K + 1) + K // 2048 + 64:]
+        _hip.call('mgv_plan_tile_counts', K, ptr(key_start), ptr(ntile), ptr(tile_first), ptr(scan_s))
+        n_active, num_tiles = int(key_start[K].item()), int(tile_first[K].item())         # second round trip
+        self.order = order[:n_active]
+        self.order_span = torch.empty(max(n_active, 1), 4, **i32)[:n_active]
+        self.tile_start, self.tile_count, self.tile_slot = (torch.empty(max(num_tiles, 1), **i32)[:num_tiles] for _ in range(3))
+        _hip.call('mgv_plan_tiles', K, T, max(L, 1), n_active, ptr(key_start), ptr(tile_first), ptr(self.order), ptr(self.in_ptr), ptr(self.out_ptr),
+                  ptr(self.tile_start), ptr(self.tile_count), ptr(self.tile_slot), ptr(self.order_span), ptr(ltp_dev))
+        # tiles grouped by slot (stable), for the per-slot weight-gradient pass of the backward sweep
+        self.slot_tiles = torch.empty(max(num_tiles, 1), **i32)[:num_tiles]
+        slot_start = torch.empty(T + 1, **i32)
+        n_s2 = _hip.call_value('mgv_count_sort_scratch_ints', num_tiles, T)
+        scratch2 = torch.empty(n_s2, **i32)
+        _hip.call('mgv_count_sort_i32', num_tiles, ptr(self.tile_slot), T, ptr(self.slot_tiles), ptr(slot_start), ptr(scratch2), n_s2)
+        host = torch.cat([ltp_dev[:max(L, 1) + 1], slot_start]).tolist()                     # third (last) round trip
+        self.level_tile_ptr = host[:max(L, 1) + 1]
+        self.slot_tile_ptr = host[max(L, 1) + 1:]
+        self.num_tiles, self.n_active, self.num_slots = num_tiles, n_active, T
+        self.has_levels = True
+        return self
+
     def set_levels(self, gate, forward_level, gate_ids):
         """Bucket the nodes a Model updates: level >= 1 and gate id in `gate_ids` (list, position =
         aggregator slot).  Mirrors `layer_mask & <gate>_mask` of the reference level loop."""
+        if self.hip:
+            done = self._set_levels_hip(gate, forward_level, gate_ids)
+            if done is not False:
+                return self
         dev = self.device
         g = gate.reshape(-1).to(dev).long()
         lv = forward_level.reshape(-1).to(dev).long()

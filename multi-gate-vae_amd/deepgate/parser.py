@@ -52,9 +52,11 @@ def forward_levels(edge_index, num_nodes):
     return level
 
 
-def parse_graph(x, edge_index, prob, tt_sim, tt_pair_index, circuit_type, gate=None, name=None):
+def parse_graph(x, edge_index, prob, tt_sim, tt_pair_index, circuit_type, gate=None, name=None, levelise=True):
     """One circuit -> field dict (parse_pyg_mlpgate).  AIG files store edge_index / tt_pair_index as [2, *]
-    (parser_func.py:46-50); the other types store [*, 2] and are transposed (parser_func_others.py:47-60)."""
+    (parser_func.py:46-50); the other types store [*, 2] and are transposed (parser_func_others.py:47-60).
+    levelise=False leaves `forward_level` / `forward_index` out: the batch is then levelised on the device
+    (GraphPlan.asap_levels, csrc/plan_build.hip) when its plan is built."""
     x = np.asarray(x)
     n = x.shape[0]
     gate_id = x[:, 1].astype(np.int64)
@@ -70,12 +72,15 @@ def parse_graph(x, edge_index, prob, tt_sim, tt_pair_index, circuit_type, gate=N
     ei = np.ascontiguousarray(ei.reshape(2, -1))
     tp = np.ascontiguousarray(tp.reshape(2, -1))
     g = np.asarray(gate, dtype=np.float32).reshape(n, 1) if gate is not None else x[:, 1:2].astype(np.float32)
-    return {
-        'x': feat, 'edge_index': ei, 'gate': g, 'forward_level': forward_levels(ei, n),
-        'forward_index': np.arange(n, dtype=np.int64), 'prob': np.asarray(prob, dtype=np.float32).reshape(n, 1),
+    out = {
+        'x': feat, 'edge_index': ei, 'gate': g, 'prob': np.asarray(prob, dtype=np.float32).reshape(n, 1),
         'tt_pair_index': tp, 'tt_sim': np.asarray(tt_sim, dtype=np.float32).reshape(-1),
         'num_nodes': n, 'name': name,          # no neg_edge_index: negatives are drawn every step (dg_ae_model_aig.py:115-119)
     }
+    if levelise:
+        out['forward_level'] = forward_levels(ei, n)
+        out['forward_index'] = np.arange(n, dtype=np.int64)
+    return out
 
 
 class NpzParser:
@@ -83,11 +88,13 @@ class NpzParser:
     (parser.py:22-41).  The parsed list is cached as `<data_dir>/inmemory_mgv/<type>.npz` like the reference's
     `inmemory/data.pt`."""
 
-    def __init__(self, data_dir, circuit_path, label_path, circuit_type, random_shuffle=True, trainval_split=0.9, seed=0):
+    def __init__(self, data_dir, circuit_path, label_path, circuit_type, random_shuffle=True, trainval_split=0.9, seed=0, levelise=True):
         """`seed` fixes the shuffle and therefore the train/val cut: every rank of a distributed job must hold the SAME
         ordered lists (GraphLoader strides them by rank), so the default is a constant, not entropy."""
         self.data_dir, self.circuit_type = data_dir, circuit_type
         graphs = self._load(data_dir, circuit_path, label_path, circuit_type)
+        if not levelise:                      # levels then come from the device builder, batch by batch
+            graphs = [{k: v for k, v in g.items() if k not in ('forward_level', 'forward_index')} for g in graphs]
         if random_shuffle:
             rng = np.random.default_rng(seed)
             graphs = [graphs[i] for i in rng.permutation(len(graphs))]

@@ -1,0 +1,214 @@
+"""GPU tests of the on-device batch builder (csrc/plan_build.hip): every array of the HIP-built GraphPlan
+equals the torch-built one (stable sorts by destination / source / (level, slot)), device ASAP levels equal the reference's
+`return_order_info` output (tests/golden/g6_loader.npz, utils/dag_utils.py:10-37,80-88) and the host levelisation, and the
+building blocks (scan, stable counting sort) hold at ragged sizes."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    return torch.device('cuda:0')
+
+
+def _plans(ei, N, monkeypatch):
+    from deepgate.graph_plan import GraphPlan
+    monkeypatch.setenv('MGV_PLAN', 'torch')
+    ref = GraphPlan(ei, N)
+    monkeypatch.setenv('MGV_PLAN', 'hip')
+    got = GraphPlan(ei, N)
+    assert got.hip and not ref.hip
+    return ref, got
+
+
+def _same(ref, got, names):
+    for n in names:
+        a, b = getattr(ref, n), getattr(got, n)
+        if torch.is_tensor(a):
+            assert a.shape == b.shape and a.dtype == b.dtype, (n, a.shape, b.shape, a.dtype, b.dtype)
+            assert torch.equal(a, b), n
+        else:
+            assert a == b, (n, a, b)
+
+
+CSR = ['in_ptr', 'in_src', 'in_dst', 'out_ptr', 'out_dst', 'out_slot']
+LEVELS = ['gslot', 'level', 'num_levels', 'order', 'order_span', 'tile_start', 'tile_count', 'tile_slot', 'slot_tiles', 'slot_tile_ptr',
+          'level_tile_ptr', 'num_tiles', 'n_active', 'num_slots']
+
+
+def _random_multigraph(rng, N, E, hub=None, hub_deg=0):
+    src = rng.integers(0, N, size=E)
+    dst = rng.integers(0, N, size=E)
+    if hub is not None:                              # one node with a very long out-list and another with a long in-list
+        src[:hub_deg] = hub
+        dst[E - hub_deg // 2:] = (hub + 1) % N
+    return np.stack([src, dst]).astype(np.int64)
+
+
+@pytest.mark.parametrize('case', ['tiny', 'empty', 'dupes', 'hub_bitonic', 'hub_rank', 'ragged'])
+def test_csr_equals_stable_sorts(case, monkeypatch):
+    dev = _dev()
+    rng = np.random.Generator(np.random.PCG64(11))
+    if case == 'tiny':
+        N, ei = 1, np.zeros((2, 0), dtype=np.int64)
+    elif case == 'empty':
+        N, ei = 777, np.zeros((2, 0), dtype=np.int64)
+    elif case == 'dupes':
+        N, ei = 50, _random_multigraph(rng, 50, 4000)              # many parallel edges: every list longer than the register path
+    elif case == 'hub_bitonic':
+        N, ei = 3000, _random_multigraph(rng, 3000, 9000, hub=7, hub_deg=3500)
+    elif case == 'hub_rank':
+        N, ei = 2049, _random_multigraph(rng, 2049, 20000, hub=2048, hub_deg=9000)      # > 4096: rank-sort path
+    else:
+        N, ei = 100003, _random_multigraph(rng, 100003, 263111)
+    ref, got = _plans(torch.from_numpy(ei).to(dev), N, monkeypatch)
+    got._check_status()
+    _same(ref, got, CSR)
+
+
+def test_out_of_range_node_ids_are_reported(monkeypatch):
+    dev = _dev()
+    from deepgate.graph_plan import GraphPlan
+    monkeypatch.setenv('MGV_PLAN', 'hip')
+    p = GraphPlan(torch.tensor([[0, 1, 9], [1, 2, 0]], device=dev), 3)
+    with pytest.raises(ValueError):
+        p._check_status()
+
+
+@pytest.mark.parametrize('ctype', ['aig', 'mig', 'xag', 'xmg'])
+def test_level_buckets_tiles_and_first_stage_classes_equal_the_torch_plan(ctype, monkeypatch):
+    dev = _dev()
+    import deepgate
+    from deepgate import synthetic as syn
+    model_mod = getattr(deepgate, 'dg_ae_model_' + ctype)
+    gate_ids = [g for _, g in model_mod.Model.GATES]
+    # ragged batch: graphs of different depth and width, so levels hold mixed gate types and partial tiles
+    graphs = [syn.make_graph(ctype, P + L * per, L, 300 + L, n_inputs=P) for P, L, per in ((200, 10, 480), (300, 17, 300), (400, 24, 210))]
+    arrays = syn.collate(graphs)
+    ei = torch.from_numpy(arrays['edge_index']).to(dev)
+    gate = torch.from_numpy(arrays['gate']).to(dev)
+    lv = torch.from_numpy(arrays['forward_level']).to(dev)
+    ref, got = _plans(ei, arrays['num_nodes'], monkeypatch)
+    monkeypatch.setenv('MGV_PLAN', 'torch')
+    ref.set_levels(gate, lv, gate_ids)
+    monkeypatch.setenv('MGV_PLAN', 'hip')
+    got.set_levels(gate, lv, gate_ids)
+    _same(ref, got, CSR + LEVELS)
+    xcls = torch.from_numpy(arrays['x'][:, 1].astype('uint8')).to(dev)
+    a, b = ref.first_stage_classes(xcls), got.first_stage_classes(xcls)
+    assert a[1] == b[1]
+    for u, v in zip((a[0], a[2], a[3], a[4]), (b[0], b[2], b[3], b[4])):
+        assert torch.equal(u, v)
+
+
+def test_bad_levels_are_rejected(monkeypatch):
+    dev = _dev()
+    from deepgate.graph_plan import GraphPlan
+    monkeypatch.setenv('MGV_PLAN', 'hip')
+    p = GraphPlan(torch.tensor([[0, 1], [1, 2]], device=dev), 3)
+    with pytest.raises(ValueError):
+        p.set_levels(torch.tensor([[0.], [1.], [1.]], device=dev), torch.tensor([0, 1, 1], device=dev), [1, 2])
+
+
+def test_device_levels_equal_the_reference_levelisation(monkeypatch):
+    dev = _dev()
+    from deepgate.graph_plan import GraphPlan
+    from deepgate.parser import forward_levels
+    monkeypatch.setenv('MGV_PLAN', 'hip')
+    z = np.load(os.path.join(GOLDEN, 'g6_loader.npz'))
+    for tag in ('aig', 'xmg'):                       # shuffled node ids; levels written by the reference's return_order_info
+        ei = z[tag + '_edge_index']
+        n = z[tag + '_x'].shape[0]
+        got = GraphPlan(torch.from_numpy(ei).to(dev), n).asap_levels().cpu().numpy()
+        assert np.array_equal(got, z[tag + '_forward_level'].astype(np.int64)), tag
+        back = GraphPlan(torch.from_numpy(np.ascontiguousarray(ei[::-1])).to(dev), n).asap_levels().cpu().numpy()
+        assert np.array_equal(back, z[tag + '_backward_level'].astype(np.int64)), tag
+    # a deep chain (more levels than the first batch of rounds) with side branches, and a large random DAG
+    rng = np.random.Generator(np.random.PCG64(5))
+    n = 3000
+    chain = np.stack([np.arange(n - 1), np.arange(1, n)])
+    extra = np.sort(rng.integers(0, n, size=(2, 4000)), axis=0)
+    extra = extra[:, extra[0] != extra[1]]
+    ei = np.concatenate([chain, extra], axis=1)
+    got = GraphPlan(torch.from_numpy(ei).to(dev), n).asap_levels().cpu().numpy()
+    assert np.array_equal(got, forward_levels(ei, n)) and got.max() == n - 1
+    with pytest.raises(ValueError):
+        GraphPlan(torch.tensor([[0, 1, 2], [1, 2, 0]], device=dev), 4).asap_levels()
+
+
+def test_a_batch_without_host_levels_trains_like_one_with(monkeypatch):
+    """NpzParser(levelise=False) graphs: the plan levelises on the device; same losses as with the host levels."""
+    dev = _dev()
+    import types
+    import deepgate
+    from deepgate import synthetic as syn
+    graphs = [syn.make_graph('aig', 1024, 30, 40 + i, n_inputs=64) for i in range(2)]
+    full = syn.collate(graphs)
+    bare = syn.collate([{k: v for k, v in g.items() if k not in ('forward_level', 'forward_index')} for g in graphs])
+    assert 'forward_level' not in bare
+    torch.manual_seed(0)
+    enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=64, s_rounds=2, t_rounds=2, layernorm=True)
+    model = deepgate.dg_ae_model_aig.Model(struct_encoder=enc, dim_hidden=64).to(dev).eval()
+    tr = deepgate.Trainer(types.SimpleNamespace(model='DG_AE'), model, training_id='lv', save_dir='/tmp/mgv_plan_test', lr=1e-4,
+                          rc_prob_func_weight=[1.0, 4.0, 4.0], device='cuda:0', batch_size=2, distributed=False)
+    with torch.no_grad():
+        a = tr.run_batch(deepgate.CircuitBatch.from_arrays(full, device=dev))
+        b = tr.run_batch(deepgate.CircuitBatch.from_arrays(bare, device=dev))
+    for k in ('recon_loss', 'prob_loss', 'func_loss'):
+        assert float(a[k]) == float(b[k]), k
+
+
+def test_scan_and_counting_sort_building_blocks():
+    dev = _dev()
+    from deepgate import _hip
+    from deepgate._hip import ptr
+    rng = np.random.Generator(np.random.PCG64(3))
+    for n in (0, 1, 2047, 2048, 2049, 1 << 20, 3_000_001):
+        x = torch.from_numpy(rng.integers(0, 5, size=n).astype(np.int32)).to(dev)
+        out = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(n // 2048 + 2, dtype=torch.int32, device=dev)
+        _hip.call('mgv_scan_exclusive_i32', n, ptr(x), ptr(out), ptr(scratch))
+        ref = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        ref[1:] = torch.cumsum(x.long(), 0)
+        assert torch.equal(out.long(), ref), n
+    for n, K in ((0, 3), (5, 1), (70000, 7), (1_234_567, 1205), (4096, 8192)):
+        key = torch.from_numpy(rng.integers(-1, K, size=n).astype(np.int32)).to(dev)
+        order = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        ks = torch.empty(K + 1, dtype=torch.int32, device=dev)
+        ns = _hip.call_value('mgv_count_sort_scratch_ints', n, K)
+        scratch = torch.empty(ns, dtype=torch.int32, device=dev)
+        _hip.call('mgv_count_sort_i32', n, ptr(key), K, ptr(order), ptr(ks), ptr(scratch), ns)
+        keep = torch.nonzero(key >= 0).reshape(-1)
+        ref = keep[torch.sort(key[keep].long(), stable=True).indices]
+        m = int(ks[K].item())
+        assert m == keep.numel() and torch.equal(order[:m].long(), ref), (n, K)
+        cnt = torch.bincount(key[keep].long(), minlength=K)
+        assert torch.equal((ks[1:] - ks[:-1]).long(), cnt)
+
+
+def test_plan_build_time_at_config_2():
+    """Not a parity test: records the cold and warm plan-build times at BASELINE config 2 (795 ms cold with torch ops)."""
+    dev = _dev()
+    import deepgate
+    from deepgate import synthetic as syn
+    from deepgate.data import plan_of
+    arrays = syn.make_batch(2, batch=16)
+    times = []
+    for _ in range(3):
+        b = deepgate.CircuitBatch.from_arrays(arrays, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        plan_of(b, [1, 2])
+        torch.cuda.synchronize()
+        times.append((time.time() - t0) * 1e3)
+    print('plan build, 16 x 65,536-node graphs: cold %.1f ms, warm %.2f ms' % (times[0], min(times[1:])))
+    assert min(times[1:]) < 50.0
