@@ -383,41 +383,41 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                     dgo[0] = s_dhz[(wc * 2 + 0) * 64 + lane]; dgo[1] = s_dhz[(wc * 2 + 1) * 64 + lane];
                     dgo[2] = dhz[0]; dgo[3] = dhz[1];
                 }
+                // first half of the gate columns for all four row tiles
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    if (half == 1) {
-                        asm volatile("" : "+v"(wd_hi_p), "+v"(wd_lo_p));
+                for (int k = 0; k < 3; ++k) {
+                    const __bf16* ph = s_dg + (k >> 1) * 2 * PE;
+                    const __bf16* pl = ph + PE;
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) { wd_hi[k] = ldfrag(wd_hi_p + (3 + k) * 512); wd_lo[k] = ldfrag(wd_lo_p + (3 + k) * 512); }
+                    for (int i = 0; i < 4; ++i) {
+                        const int off = (i * 16 + r) * LDP + 32 * (k & 1) + 8 * q;
+                        mma_x3(dgo[i], wd_hi[k], wd_lo[k], ldfrag(ph + off), ldfrag(pl + off));
                     }
+                }
+                asm volatile("" : "+v"(wd_hi_p), "+v"(wd_lo_p));
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { wd_hi[k] = ldfrag(wd_hi_p + (3 + k) * 512); wd_lo[k] = ldfrag(wd_lo_p + (3 + k) * 512); }
+                // second half row tile by row tile; each finished accumulator leaves at once, straight from the registers: lane (r, q)
+                // holds 16 contiguous bytes of row 16 i + r, the four column waves complete each 256-byte row within the same phase
+                // and L2 merges the 64-byte pieces.  No staging tile, no barrier behind it: the next row phase writes planes / dY /
+                // xe / deg,cls only behind its barrier (0), region C is rewritten after its barrier (1).
+                float* go = m ? a.g_direct_out : a.g_agg_out;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
-                        const int ks = 3 * half + k;
+                        const int ks = 3 + k;
                         const int p = (ks >> 1) == 2 ? 2 + m : (ks >> 1);
                         const __bf16* ph = s_dg + p * 2 * PE;
-                        const __bf16* pl = ph + PE;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int off = (i * 16 + r) * LDP + 32 * (ks & 1) + 8 * q;
-                            mma_x3(dgo[i], wd_hi[k], wd_lo[k], ldfrag(ph + off), ldfrag(pl + off));
-                        }
+                        const int off = (i * 16 + r) * LDP + 32 * (ks & 1) + 8 * q;
+                        mma_x3(dgo[i], wd_hi[k], wd_lo[k], ldfrag(ph + off), ldfrag(ph + PE + off));
                     }
+                    const int64_t node = base + i * 16 + r;
+                    if (node < a.N) *reinterpret_cast<f32x4*>(go + node * H + c0) = dgo[i];
                 }
             }
         }
         STAMP(9);
-        // ---- outputs straight from the accumulators: lane (r, q) holds 16 contiguous bytes of row 16 i + r; the four column waves
-        //      complete each 256-byte row within the same phase and L2 merges the 64-byte pieces.  No staging tile, no barrier:
-        //      the next row phase writes planes / dY / xe / deg,cls (dead since (4)), region C is rewritten after its barrier (1).
-        if (need_dgrad) {
-            LANE_IDS
-            float* go = m ? a.g_direct_out : a.g_agg_out;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int64_t node = base + i * 16 + r;
-                if (node < a.N) *reinterpret_cast<f32x4*>(go + node * H + c0) = dgo[i];
-            }
-        }
         STAMP(13);
         // no barrier: the next row phase writes planes / dY / xe / deg,cls (all dead since (5)); region C is rewritten
         // only after the next tile's barrier (1)
