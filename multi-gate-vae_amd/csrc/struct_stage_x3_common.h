@@ -10,6 +10,7 @@ namespace mgv {
 struct StageX3Args {
     unsigned long long* stamps;   // diagnostic build only (MGV_STAMPS): [8 waves][16 phases] cycle sums
     int xcd;                      // 1: XCD-contiguous tile order (default), 0: round-robin (MGV_XCD_TILES=0, A/B measurements)
+    int prefetch;                 // bwd2: 1: L2 prefetch of the next tile's rows (default), 0: off (MGV_ROW_PREFETCH=0, A/B measurements)
     int64_t N;
     const float* h_in;
     const int32_t* ptr;
