@@ -148,6 +148,9 @@ int mgv_func_sweep_bwd(int H, int64_t N, int T, int num_levels, const int32_t* l
  * it; the small gradients (d_attn_u, dbvc, dbih, dbhh) are summed per workgroup in `scratch` too.
  * scratch_elems >= n_active * 5H + (tiles of the widest level) * T * 11H floats, n_active = length of `order`.
  * dWvc stays fp32 [T][3H][2H] and is ADDED to; ghs[N][H] is WRITTEN for every node (no zero fill needed). */
+/* hf[v] = 0 for the nodes the sweep never updates (gslot[v] == 255; dg_ae_model_aig.py:61 zero-fills the whole state):
+ * with it the caller hands the sweep an UNINITIALISED hf instead of a zero-filled one */
+int mgv_sweep_zero_inactive(int H, int64_t N, const uint8_t* gslot, float* hf, void* stream);
 int mgv_func_sweep_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
                           const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
                           const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,

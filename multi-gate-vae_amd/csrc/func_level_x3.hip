@@ -646,6 +646,15 @@ __global__ __launch_bounds__(kThreads) void k_level_pull_inactive_x3(LevelX3Args
     }
 }
 
+// hf rows of the nodes the sweep never updates stay zero (dg_ae_model_aig.py:61: hf starts as zeros): written here, one
+// sixteenth of the rows at the baseline shapes, instead of zero-filling the whole [N, H] state in front of the sweep
+__global__ __launch_bounds__(kThreads) void k_zero_inactive_rows(int64_t N, int H, const uint8_t* gslot, float* hf) {
+    const int lpr = H / 4, lr = threadIdx.x % lpr;
+    const int64_t stride = (int64_t)gridDim.x * (kThreads / lpr);
+    for (int64_t node = (int64_t)blockIdx.x * (kThreads / lpr) + threadIdx.x / lpr; node < N; node += stride)
+        if (gslot[node] == kNoGateX) st4(hf + node * H + 4 * lr, zero4());
+}
+
 // dWvc[g] += sum over the rows of slot g of dG[row]^T zbar[row], from the rows the level kernels left behind.
 // Persistent workgroups walk the slot's tile list; a tile's fp32 rows are split into bf16 hi/lo planes in LDS
 // and both MFMA operands are read transposed from them; the next tile's rows are in flight (registers) meanwhile.
@@ -789,6 +798,15 @@ extern "C" int mgv_diag_set_level_stamps(void* p) { g_lvl_stamps = static_cast<u
 #else
 #define MGV_SET_LVL_STAMPS(a)
 #endif
+
+extern "C" int mgv_sweep_zero_inactive(int H, int64_t N, const uint8_t* gslot, float* hf, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && (H == 16 || H == 32 || H == 64) && (N == 0 || (gslot && hf)));
+    if (N == 0) return MGV_OK;
+    const int rows_per_block = mgv::kThreads / (H / 4);
+    hipLaunchKernelGGL(mgv::k_zero_inactive_rows, dim3(mgv::grid_for((N + rows_per_block - 1) / rows_per_block, 8)), dim3(mgv::kThreads), 0,
+                       static_cast<hipStream_t>(stream), N, H, gslot, hf);
+    MGV_LAUNCH_RET();
+}
 
 extern "C" int mgv_func_sweep_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
                                      const int32_t* order, const int32_t* order_span, const int32_t* tile_start,

@@ -369,9 +369,13 @@ class FuncSweepFn(torch.autograd.Function):
         par = [check(t.detach().contiguous(), F32, 'sweep parameter') for t in (attn_u, Wvc, bvc, bih, bhh)]
         T = par[0].shape[0]
         assert plan.has_levels and plan.num_slots == T and plan.N == N
-        hf = torch.zeros(N, H, dtype=F32, device=hsd.device)
         ltp = (_hip.ctypes.c_int32 * len(plan.level_tile_ptr))(*plan.level_tile_ptr)
         wpack = sweep_wpack(par[1]) if (use_x3(H) and os.environ.get('MGV_SWEEP_X3', '1') != '0') else None
+        if wpack is not None:
+            hf = torch.empty(N, H, dtype=F32, device=hsd.device)          # every updated row is written by its level; the rest here
+            _hip.call('mgv_sweep_zero_inactive', H, N, ptr(plan.gslot), ptr(hf))
+        else:
+            hf = torch.zeros(N, H, dtype=F32, device=hsd.device)
         if wpack is not None:
             _hip.call('mgv_func_sweep_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.order_span),
                       ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
