@@ -209,6 +209,12 @@ int mgv_neg_bucket(int64_t E, const int64_t* neg_src, const int64_t* neg_dst, co
  * 0 sum dis, 1 sum dis^2, 2 sum tt, 3 sum tt^2, 4 sum |zd-zt| (loss = ws[4]/P), 5-6 backward sums. */
 int mgv_func_loss_fwd(int H, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b,
                       const float* tt, float eps, float* dis, double* ws, void* stream);
+/* the same gradient without atomics and without a zero-filled output: every node PULLS over the pairs it belongs to, given
+ * the pair lists grouped by first member (a_ptr[N+1], a_pair[P] = pair ids) and by second member (b_ptr, b_pair) — e.g. from
+ * mgv_plan_csr over (pair_a, pair_b) with its edge-id outputs; dhf[N][H] is WRITTEN for every node; bit-reproducible */
+int mgv_func_loss_bwd_csr(int H, int64_t N, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b, const float* tt_sim,
+                          const float* dis, float eps, const double* workspace8, const float* grad_loss, const int32_t* a_ptr,
+                          const int32_t* a_pair, const int32_t* b_ptr, const int32_t* b_pair, float* dhf, void* stream);
 int mgv_func_loss_bwd(int H, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b,
                       const float* tt, const float* dis, float eps, const double* ws, const float* gscale,
                       float* dhf, void* stream);
@@ -259,8 +265,8 @@ int mgv_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, fl
 int mgv_scan_exclusive_i32(int64_t n, const int32_t* in, int32_t* out, int32_t* scratch, void* stream);   /* out[n] = total; scratch: n/2048 + 2 */
 int mgv_plan_csr_scratch_ints(int64_t N, int64_t E);                                                  /* a size, not a status */
 int mgv_plan_csr(int64_t N, int64_t E, const int64_t* src, const int64_t* dst, int32_t* in_ptr, int32_t* in_src, int32_t* in_dst,
-                 int32_t* out_ptr, int32_t* out_dst, int32_t* out_slot, int32_t* scratch, int64_t scratch_ints, int32_t* status,
-                 void* stream);
+                 int32_t* out_ptr, int32_t* out_dst, int32_t* out_slot, int32_t* in_eid /* NULL or [E]: edge id per in-CSR slot */,
+                 int32_t* out_eid /* NULL or [E] */, int32_t* scratch, int64_t scratch_ints, int32_t* status, void* stream);
 /* ASAP levels by frontier relaxation over the out-CSR; `rounds` level steps are enqueued; done[0] == N afterwards iff complete.
  * scratch: 3 N + rounds + 2 ints */
 int mgv_plan_levels(int64_t N, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_dst, int32_t* level, int rounds,

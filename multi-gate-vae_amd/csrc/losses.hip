@@ -312,6 +312,50 @@ __global__ __launch_bounds__(kThreads) void k_func_bwd(int64_t P, const float* h
     }
 }
 
+// The same gradient pulled per node over the pairs it belongs to (lists grouped by first / by second member): every output row is
+// written exactly once, in a fixed order — no zero fill in front, no float atomics, bit-reproducible.  A pair is visited twice
+// (once from each member), which costs one extra gather of its other row.
+template <int H>
+__global__ __launch_bounds__(kThreads) void k_func_bwd_pull(int64_t N, int64_t P, const float* hf, const int64_t* pa, const int64_t* pb,
+                                                            const float* tt, const float* dis, float eps, const double* ws, const float* gscale,
+                                                            const int32_t* a_ptr, const int32_t* a_pair, const int32_t* b_ptr,
+                                                            const int32_t* b_pair, float* dhf) {
+    constexpr int LPR = H / 4, RPB = kThreads / LPR;
+    const int lr = threadIdx.x % LPR;
+    const ZStats z = zstats(ws, P);
+    const float g = *gscale;
+    const float mean_s = (float)(ws[5] / (double)P), ssz = (float)(ws[6] / ((double)P - 1.0));
+    const float k = g / (float)P * z.inv_sd;
+    for (int64_t v = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR; v < N; v += (int64_t)gridDim.x * RPB) {
+        const float4 own = ld4(hf + v * H + 4 * lr);
+        const float oo = group_sum<LPR>(dot4(own, own));
+        const float ro = sqrtf(oo), no = fmaxf(ro, eps);
+        float4 acc = zero4();
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {
+            const int32_t* lp = side ? b_ptr : a_ptr;
+            const int32_t* lq = side ? b_pair : a_pair;
+            for (int e = lp[v]; e < lp[v + 1]; ++e) {
+                const int p = lq[e];
+                const int64_t u = side ? pa[p] : pb[p];
+                const float4 oth = ld4(hf + u * H + 4 * lr);
+                const float xy = group_sum<LPR>(dot4(own, oth));
+                const float uu = group_sum<LPR>(dot4(oth, oth));
+                const float zd = (dis[p] - z.mu_d) * z.inv_sd, zt = (tt[p] - z.mu_t) * z.inv_st;
+                const float diff = zd - zt;
+                const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                const float dc = -k * (sg - mean_s - zd * ssz);              // dL/d cos
+                const float nu = fmaxf(sqrtf(uu), eps);
+                const float inv = 1.0f / (no * nu);
+                const float ko = ro > eps ? xy * inv / (no * no) : 0.f;      // the norm factor only depends on the own row where it is not clamped
+                acc = fma4(dc * inv, oth, acc);
+                acc = fma4(-dc * ko, own, acc);
+            }
+        }
+        st4(dhf + v * H + 4 * lr, acc);
+    }
+}
+
 // ---------------------------------------------------------------------------------- sampler + KL
 __device__ __forceinline__ uint32_t mix32(uint64_t x) {
     x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -467,6 +511,21 @@ extern "C" int mgv_func_loss_fwd(int H, int64_t P, const float* hf, const int64_
     MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_func_dist<HH>), dim3(mgv::items_grid(P, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st,
                                          P, hf, pair_a, pair_b, tt, eps, dis, ws));
     hipLaunchKernelGGL(mgv::k_func_l1, dim3(mgv::items_grid(P, mgv::kThreads)), dim3(mgv::kThreads), 0, st, P, dis, tt, ws);
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_func_loss_bwd_csr(int H, int64_t N, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b, const float* tt,
+                                     const float* dis, float eps, const double* ws, const float* gscale, const int32_t* a_ptr,
+                                     const int32_t* a_pair, const int32_t* b_ptr, const int32_t* b_pair, float* dhf, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && P >= 2 && hf && pair_a && pair_b && tt && dis && ws && gscale && a_ptr && a_pair && b_ptr && b_pair && dhf);
+    if (N == 0) return MGV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (H) {
+        case 16: hipLaunchKernelGGL((mgv::k_func_bwd_pull<16>), dim3(mgv::items_grid(N, mgv::kThreads / 4)), dim3(mgv::kThreads), 0, st, N, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, a_ptr, a_pair, b_ptr, b_pair, dhf); break;
+        case 32: hipLaunchKernelGGL((mgv::k_func_bwd_pull<32>), dim3(mgv::items_grid(N, mgv::kThreads / 8)), dim3(mgv::kThreads), 0, st, N, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, a_ptr, a_pair, b_ptr, b_pair, dhf); break;
+        case 64: hipLaunchKernelGGL((mgv::k_func_bwd_pull<64>), dim3(mgv::items_grid(N, mgv::kThreads / 16)), dim3(mgv::kThreads), 0, st, N, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, a_ptr, a_pair, b_ptr, b_pair, dhf); break;
+        default: return MGV_EUNSUPPORTED;
+    }
     MGV_LAUNCH_RET();
 }
 

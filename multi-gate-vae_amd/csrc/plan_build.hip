@@ -341,11 +341,12 @@ extern "C" int mgv_scan_exclusive_i32(int64_t n, const int32_t* in, int32_t* out
 
 extern "C" int mgv_plan_csr_scratch_ints(int64_t N, int64_t E) { return (int)(2 * N + 4 * E + (N + E) / kScanItems + 64); }
 
-/* scratch (int32): cur_in[N] cur_out[N] eid_in[E] eid_out[E] pos_in[E] tmp[E] scan[...] flags[8]; flags are returned in status[0..1]
+/* in_eid / out_eid (optional, E ints each): the original edge id behind every in- / out-CSR slot.
+ * scratch (int32): cur_in[N] cur_out[N] eid_in[E] eid_out[E] pos_in[E] tmp[E] scan[...] flags[8]; flags are returned in status[0..1]
  * (status[0]: 1 = node id out of range; device memory, 2 ints, written asynchronously) */
 extern "C" int mgv_plan_csr(int64_t N, int64_t E, const int64_t* src, const int64_t* dst, int32_t* in_ptr, int32_t* in_src, int32_t* in_dst,
-                            int32_t* out_ptr, int32_t* out_dst, int32_t* out_slot, int32_t* scratch, int64_t scratch_ints, int32_t* status,
-                            void* stream) {
+                            int32_t* out_ptr, int32_t* out_dst, int32_t* out_slot, int32_t* in_eid, int32_t* out_eid, int32_t* scratch,
+                            int64_t scratch_ints, int32_t* status, void* stream) {
     MGV_CHECK_ARG(N >= 0 && E >= 0 && N < (1LL << 31) && E < (1LL << 31) && in_ptr && out_ptr && scratch && status);
     MGV_CHECK_ARG(scratch_ints >= mgv_plan_csr_scratch_ints(N, E));
     MGV_CHECK_ARG(E == 0 || (src && dst && in_src && in_dst && out_dst && out_slot));
@@ -378,6 +379,8 @@ extern "C" int mgv_plan_csr(int64_t N, int64_t E, const int64_t* src, const int6
         hipLaunchKernelGGL(k_sort_lists, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, ptr, eid, heavy, n_heavy);
         hipLaunchKernelGGL(k_sort_heavy, dim3(256), dim3(1024), 0, st, heavy, n_heavy, ptr, eid, tmp);
     }
+    if (in_eid) hipMemcpyAsync(in_eid, eid_in, E * sizeof(int32_t), hipMemcpyDeviceToDevice, st);        // original edge id of every CSR slot
+    if (out_eid) hipMemcpyAsync(out_eid, eid_out, E * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
     hipLaunchKernelGGL(k_csr_finish_in, dim3(blocks_for(E)), dim3(256), 0, st, E, src, dst, eid_in, in_src, in_dst, pos_in);
     hipLaunchKernelGGL(k_csr_finish_out, dim3(blocks_for(E)), dim3(256), 0, st, E, dst, eid_out, pos_in, out_dst, out_slot);
     MGV_LAUNCH_RET();

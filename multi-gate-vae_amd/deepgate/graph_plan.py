@@ -67,7 +67,7 @@ class GraphPlan:
         scratch = torch.empty(n_s, **i32)
         status = torch.empty(2, **i32)
         _hip.call('mgv_plan_csr', N, E, ptr(src), ptr(dst), ptr(self.in_ptr), ptr(self.in_src), ptr(self.in_dst), ptr(self.out_ptr),
-                  ptr(self.out_dst), ptr(self.out_slot), ptr(scratch), n_s, ptr(status))
+                  ptr(self.out_dst), ptr(self.out_slot), None, None, ptr(scratch), n_s, ptr(status))
         self._status = status            # read together with the level checks (one host round trip per batch)
         self._keep = (src, dst)
 

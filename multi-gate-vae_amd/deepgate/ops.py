@@ -555,11 +555,29 @@ def l1_loss(x, target):
     return L1LossFn.apply(x, target)
 
 
+def pair_lists(tt_pair_index, num_nodes):
+    """The truth-table pairs grouped by first and by second member: (a_ptr[N+1], a_pair[P], b_ptr[N+1], b_pair[P]), pair ids in
+    their original order inside a group (csrc/plan_build.hip).  Static per batch: the trainer caches it on the batch."""
+    pa, pb = _edge_rows(tt_pair_index)
+    P, N, dev = pa.numel(), int(num_nodes), pa.device
+    i32 = dict(dtype=I32, device=dev)
+    a_ptr, b_ptr = torch.empty(N + 1, **i32), torch.empty(N + 1, **i32)
+    junk = torch.empty(4, max(P, 1), **i32)                      # neighbour / slot arrays of the CSR build, not needed here
+    a_pair, b_pair = torch.empty(max(P, 1), **i32), torch.empty(max(P, 1), **i32)
+    n_s = _hip.call_value('mgv_plan_csr_scratch_ints', N, P)
+    scratch = torch.empty(n_s, **i32)
+    status = torch.empty(2, **i32)
+    _hip.call('mgv_plan_csr', N, P, ptr(pa), ptr(pb), ptr(b_ptr), ptr(junk[0]), ptr(junk[1]), ptr(a_ptr), ptr(junk[2]), ptr(junk[3]),
+              ptr(b_pair), ptr(a_pair), ptr(scratch), n_s, ptr(status))
+    return a_ptr, a_pair, b_ptr, b_pair
+
+
 class FuncLossFn(torch.autograd.Function):
-    """L1(z(1 - cos(hf[a], hf[b])), z(tt_sim)) with z = zero_normalization (trainer.py:158-163)."""
+    """L1(z(1 - cos(hf[a], hf[b])), z(tt_sim)) with z = zero_normalization (trainer.py:158-163).
+    `lists` (optional, from pair_lists): backward without atomics and without a zero-filled gradient."""
 
     @staticmethod
-    def forward(ctx, hf, tt_pair_index, tt_sim):
+    def forward(ctx, hf, tt_pair_index, tt_sim, lists=None):
         hfd = check(hf.detach().contiguous(), F32, 'hf')
         pa, pb = _edge_rows(tt_pair_index)
         tt = check(tt_sim.detach().to(F32).contiguous(), F32, 'tt_sim')
@@ -568,20 +586,33 @@ class FuncLossFn(torch.autograd.Function):
         ws = torch.zeros(8, dtype=torch.float64, device=hfd.device)
         _hip.call('mgv_func_loss_fwd', H, P, ptr(hfd), ptr(pa), ptr(pb), ptr(tt), 1e-8, ptr(dis), ptr(ws))
         ctx.save_for_backward(hfd, pa, pb, tt, dis, ws)
+        ctx.lists = lists
         return (ws[4] / P).to(F32)
 
     @staticmethod
     def backward(ctx, g):
         hfd, pa, pb, tt, dis, ws = ctx.saved_tensors
-        dhf = torch.zeros_like(hfd)
         gs = g.detach().to(F32).reshape(1).contiguous()
+        if ctx.lists is not None:
+            dhf = torch.empty_like(hfd)
+            _hip.call('mgv_func_loss_bwd_csr', hfd.shape[1], hfd.shape[0], pa.numel(), ptr(hfd), ptr(pa), ptr(pb), ptr(tt), ptr(dis), 1e-8,
+                      ptr(ws), ptr(gs), *[ptr(t) for t in ctx.lists], ptr(dhf))
+            return dhf, None, None, None
+        dhf = torch.zeros_like(hfd)
         _hip.call('mgv_func_loss_bwd', hfd.shape[1], pa.numel(), ptr(hfd), ptr(pa), ptr(pb), ptr(tt), ptr(dis), 1e-8,
                   ptr(ws), ptr(gs), ptr(dhf))
-        return dhf, None, None
+        return dhf, None, None, None
 
 
-def func_loss(hf, tt_pair_index, tt_sim):
-    return FuncLossFn.apply(hf, tt_pair_index, tt_sim)
+def func_loss(hf, tt_pair_index, tt_sim, cache=None):
+    """`cache`: any object that lives as long as the pairs do (the batch): the grouped pair lists are built once and kept on it."""
+    lists = None
+    if cache is not None and hf.is_cuda and tt_pair_index.shape[1] >= 2:
+        lists = getattr(cache, '_mgv_pair_lists', None)
+        if lists is None or lists[0].numel() != hf.shape[0] + 1 or lists[1].device != hf.device:
+            lists = pair_lists(tt_pair_index, hf.shape[0])
+            cache._mgv_pair_lists = lists
+    return FuncLossFn.apply(hf, tt_pair_index, tt_sim, lists)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -186,7 +186,7 @@ class Trainer():
             loss_status['kl_loss'] = s_kl + t_kl          # computed, not added (as in the reference)
         prob = self.model.pred_prob(hf)
         loss_status['prob_loss'] = self.reg_loss(prob, batch['prob'])
-        loss_status['func_loss'] = ops.func_loss(hf, batch['tt_pair_index'], batch['tt_sim'])
+        loss_status['func_loss'] = ops.func_loss(hf, batch['tt_pair_index'], batch['tt_sim'], cache=batch)
         loss_status['confusion'] = self.model.last_confusion
         return loss_status
 

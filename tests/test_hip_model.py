@@ -257,6 +257,18 @@ def test_func_loss_decoder_and_confusion_vs_reference_fixture():
     close(fl, z['fl_loss'], rtol=1e-5, msg='func loss')
     fl.backward()
     close(hf.grad, z['fl_grad_hf'], rtol=1e-3, atol=1e-4, msg='func loss grad')
+    # the pull-based backward (pairs grouped per node by csrc/plan_build.hip; no atomics, no zero fill) against the same fixture;
+    # the fixture's random pairs contain repeated nodes and may contain a == b
+    holder = types.SimpleNamespace()
+    hf2 = torch.tensor(z['fl_hf'], device=dev, requires_grad=True)
+    fl2 = ops.func_loss(hf2, torch.tensor(z['fl_pairs'], device=dev), torch.tensor(z['fl_tt'], device=dev), cache=holder)
+    assert hasattr(holder, '_mgv_pair_lists') and float(fl2) == float(fl)
+    fl2.backward()
+    close(hf2.grad, z['fl_grad_hf'], rtol=1e-3, atol=1e-4, msg='func loss grad (pull)')
+    assert float((hf2.grad - hf.grad).abs().max()) <= 1e-6 * float(hf.grad.abs().max()) + 1e-9
+    hf3 = hf2.detach().clone().requires_grad_(True)
+    ops.func_loss(hf3, torch.tensor(z['fl_pairs'], device=dev), torch.tensor(z['fl_tt'], device=dev), cache=holder).backward()
+    assert torch.equal(hf3.grad, hf2.grad)                 # bit-reproducible
     dec = DirectedInnerProductDecoder()
     s, t = torch.tensor(z['dec_s'], device=dev), torch.tensor(z['dec_t'], device=dev)
     ei = torch.tensor(z['dec_edge_index'], device=dev)
