@@ -97,16 +97,23 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
             wuh[ks][g] = ldfrag(a.wpack + 2 * BLK + wo); wul[ks][g] = ldfrag(a.wpack + 3 * BLK + wo);
         }
 
+    // Index pipeline, two LDS buffers: while tile t runs, buffer b holds the CSR pointers / neighbour ids of tile t, buffer b^1
+    // those of tile t+1 (committed at the end of tile t-1); the ids of tile t+2 are requested after tile t's dense part and committed
+    // into buffer b at its end, a whole tile before their row phase.  (An L2 prefetch of tile t+1's rows from here was measured: +8 %
+    // time, the kernel sits at the CU's memory-instruction rate and every extra load costs; the backward kernel, which idles longer, keeps it.)
     int* idx_base = reinterpret_cast<int*>(smem_raw + M::f_idx);
     const TileSeq seq = tile_seq(ntiles, a.xcd);
-    int rp = ptr_prefetch(a, seq.at(0), ntiles);
-    if (tid <= kTileRows) idx_lds(idx_base, 0).ptr[tid] = rp;
-    __syncthreads();
     int ri[kIdxCap / kThreadsF];
-    idx_prefetch<kThreadsF>(a, idx_lds(idx_base, 0).ptr, ri);
-    idx_commit<kThreadsF>(idx_lds(idx_base, 0).idx, ri);
-    tile_dmax(idx_lds(idx_base, 0).ptr, idx_lds(idx_base, 0).dmax());
-    rp = ptr_prefetch(a, seq.at(1), ntiles);
+    int rp;
+    for (int k = 0; k < 2; ++k) {
+        rp = ptr_prefetch(a, seq.at(k), ntiles);
+        if (tid <= kTileRows) idx_lds(idx_base, k).ptr[tid] = rp;
+        __syncthreads();
+        idx_prefetch<kThreadsF>(a, idx_lds(idx_base, k).ptr, ri);
+        idx_commit<kThreadsF>(idx_lds(idx_base, k).idx, ri);
+        tile_dmax(idx_lds(idx_base, k).ptr, idx_lds(idx_base, k).dmax());
+    }
+    rp = ptr_prefetch(a, seq.at(2), ntiles);
     __syncthreads();
     int b = 0;
     STAMP_DECL
@@ -132,14 +139,10 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
                 if (lr == 0) { sv.deg[row] = deg[rr]; sv.cls[row] = cls[rr]; }
             }
         }
-        if (tid <= kTileRows) idx_lds(idx_base, b ^ 1).ptr[tid] = rp;       // pointers of the next tile (requested one tile ago)
         STAMP(0);
         __syncthreads();
         STAMP(1);
-        // next tile's indices and the tile after's pointers fly during the dense part + epilogue
-        idx_prefetch<kThreadsF>(a, idx_lds(idx_base, b ^ 1).ptr, ri);
-        rp = ptr_prefetch(a, seq.at(it + 2), ntiles);
-        tile_dmax(idx_lds(idx_base, b ^ 1).ptr, idx_lds(idx_base, b ^ 1).dmax());
+        if (tid <= kTileRows) idx_lds(idx_base, b).ptr[tid] = rp;           // this tile's index buffer is dead: pointers of tile t+2 (requested one tile ago)
         // ---- dense part: LDS fragments x register-resident weights
         f32x4 ar[S::RTW], az[S::RTW], ani[S::RTW], anh[S::RTW];
 #pragma unroll
@@ -156,8 +159,12 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
                 mma_x3(ani[i], ah, al, wch[ks][2], wcl[ks][2]); mma_x3(anh[i], hh, hl, wuh[ks][2], wul[ks][2]);
             }
         STAMP(2);
-        __syncthreads();        // s_pre overlays the agg planes
+        __syncthreads();        // s_pre overlays the agg planes; pointers of tile t+2 are in buffer b
         STAMP(3);
+        // ids of tile t+2 and pointers of tile t+3 fly during the epilogue
+        idx_prefetch<kThreadsF>(a, idx_lds(idx_base, b).ptr, ri);
+        rp = ptr_prefetch(a, seq.at(it + 3), ntiles);
+        tile_dmax(idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).dmax());
         {
             const int col = wc * 16 + r;
             const float bcr = sv.bc[col], bcz = sv.bc[H + col], bcn = sv.bc[2 * H + col];
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
             }
             if (node < a.N) st4(a.h_out + node * H + 4 * lr, v);
         }
-        idx_commit<kThreadsF>(idx_lds(idx_base, b ^ 1).idx, ri);
+        idx_commit<kThreadsF>(idx_lds(idx_base, b).idx, ri);               // ids of tile t+2 replace this tile's
         STAMP(7);
         __syncthreads();
     }
