@@ -24,6 +24,11 @@ __device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) 
 }
 
 __device__ __forceinline__ bf16x8 ldfrag(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// the same from a pointer known to be GLOBAL memory although the compiler cannot see it (a pointer that went through an opaque
+// asm statement is generic: its loads become flat_load, which also occupy the LDS counter and queue)
+__device__ __forceinline__ bf16x8 ldfrag_global(const __bf16* p) {
+    return *(const __attribute__((address_space(1))) bf16x8*)p;
+}
 __device__ __forceinline__ void st_bf4(__bf16* p, const bf16x4& v) { *reinterpret_cast<bf16x4*>(p) = v; }
 
 __device__ __forceinline__ f32x4 mfma_bf16(const bf16x8& a, const bf16x8& b, f32x4 c) {

@@ -100,10 +100,10 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
     const __bf16* wr_lo_p_ = a.wpack + (2 * m + 1) * BLK + wc * 2 * 512 + lane0 * 8;
     // dgrad fragments (rows = output columns of tile wc, k = the 192 gate columns): 12 KB per wave, re-read from L2 every
     // tile in ONE burst issued in front of the weight-gradient MFMAs that cover its latency
-    const __bf16* wd_hi_p_ = a.wpack + (4 + 2 * m) * BLK + wc * 6 * 512 + lane0 * 8;
-    const __bf16* wd_lo_p_ = a.wpack + (5 + 2 * m) * BLK + wc * 6 * 512 + lane0 * 8;
+    // (scalar base + 32-bit lane offset: global_load with an SGPR address, no 64-bit pointer registers to keep alive)
+    const int wd_off = (4 + 2 * m) * BLK + wc * 6 * 512;
 
-    const __bf16 *wr_hi_p = wr_hi_p_, *wr_lo_p = wr_lo_p_, *wd_hi_p = wd_hi_p_, *wd_lo_p = wd_lo_p_;
+    const __bf16 *wr_hi_p = wr_hi_p_, *wr_lo_p = wr_lo_p_;
     // ---- persistent accumulators
     f32x4 gW[3][4];                         // 2x2 block of this wave's matrix, per gate (wgrad_blk_x3)
     f32x4 gX[2];                            // bias-type gradients of planes p = m (pp 0) and 2 + m (pp 1), gate-column tile wc
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
-                wr_hi[ks][g] = ldfrag(wr_hi_p + (g * 8 + ks) * 512);
-                wr_lo[ks][g] = ldfrag(wr_lo_p + (g * 8 + ks) * 512);
+                wr_hi[ks][g] = ldfrag_global(wr_hi_p + (g * 8 + ks) * 512);
+                wr_lo[ks][g] = ldfrag_global(wr_lo_p + (g * 8 + ks) * 512);
             }
     }
     STAMP_DECL
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
         STAMP(5);
         // ---- P3. LayerNorm + GRU backward; gate gradients to the planes
         f32x4 dhz[2];
+        float lnw_acc[4] = {0.f, 0.f, 0.f, 0.f}, lnb_acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int il = 0; il < 2; ++il) {
             LANE_IDS
@@ -324,17 +325,11 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                 const float4 gm = ld4(sv.lnw + c0);
                 const float gm_[4] = {gm.x, gm.y, gm.z, gm.w};
                 const float shift = mw[il] - mean;
-                float lw_[4], lb_[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xhat = (vd[il][e] + shift) * rstd;
-                    lw_[e] = group_sum<16>(dy_[e] * xhat); lb_[e] = group_sum<16>(dy_[e]);
+                    lnw_acc[e] += dy_[e] * xhat; lnb_acc[e] += dy_[e];      // this lane's two nodes first, ONE cross-lane sum per tile
                     dh[e] = rstd * (dy_[e] * gm_[e] - c1 - xhat * c2);
-                }
-                if (r == 0) {
-                    float* acc = s_lnacc + w * 32 + 4 * q;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { acc[e] += lw_[e]; acc[16 + e] += lb_[e]; }
                 }
             } else {
 #pragma unroll
@@ -363,6 +358,17 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             st_bf4(dst + 6 * PE, hi); st_bf4(dst + 7 * PE, lo);
             if (m == 0) s_dhz[(wc * 2 + il) * 64 + lane] = dhz[il];
         }
+        if (has_ln) {
+            LANE_IDS
+            float lw_[4], lb_[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lw_[e] = group_sum<16>(lnw_acc[e]); lb_[e] = group_sum<16>(lnb_acc[e]); }
+            if (r == 0) {
+                float* acc = s_lnacc + w * 32 + 4 * q;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { acc[e] += lw_[e]; acc[16 + e] += lb_[e]; }
+            }
+        }
         if ((pf0 ^ pf1) == 0x7fc12345u && a.stamps) a.stamps[0] = pf0;     // keeps the prefetch loads alive; never true in practice
         STAMP(6);
         __syncthreads();                                    // (4) gate-gradient planes, dh*z hand-off, next tile's indices
@@ -381,10 +387,12 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             // front of one k-step of these MFMAs.
             const int it0 = 2 * (wc >> 1), jt0 = 2 * (wc & 1), ig = wc & 1;
             bf16x8 wd_hi[3], wd_lo[3];
-            asm volatile("" : "+v"(wd_hi_p), "+v"(wd_lo_p));
+            int oz = 0;
+            asm volatile("" : "+s"(oz));                    // opaque per tile: keeps the (loop-invariant) loads inside the loop
+            const __bf16* wd_p = a.wpack + wd_off + oz;
             if (need_dgrad) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { wd_hi[k] = ldfrag(wd_hi_p + k * 512); wd_lo[k] = ldfrag(wd_lo_p + k * 512); }
+                for (int k = 0; k < 3; ++k) { wd_hi[k] = ldfrag_global(wd_p + k * 512 + lane * 8); wd_lo[k] = ldfrag_global(wd_p + BLK + k * 512 + lane * 8); }
             }
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {
@@ -426,9 +434,8 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                         mma_x3(dgo[i], wd_hi[k], wd_lo[k], ldfrag(ph + off), ldfrag(pl + off));
                     }
                 }
-                asm volatile("" : "+v"(wd_hi_p), "+v"(wd_lo_p));
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { wd_hi[k] = ldfrag(wd_hi_p + (3 + k) * 512); wd_lo[k] = ldfrag(wd_lo_p + (3 + k) * 512); }
+                for (int k = 0; k < 3; ++k) { wd_hi[k] = ldfrag_global(wd_p + (3 + k) * 512 + lane * 8); wd_lo[k] = ldfrag_global(wd_p + BLK + (3 + k) * 512 + lane * 8); }
                 // second half row tile by row tile; each finished accumulator leaves at once, straight from the registers: lane (r, q)
                 // holds 16 contiguous bytes of row 16 i + r, the four column waves complete each 256-byte row within the same phase
                 // and L2 merges the 64-byte pieces.  No staging tile, no barrier behind it: the next row phase writes planes / dY /
