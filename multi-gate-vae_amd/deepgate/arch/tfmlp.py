@@ -3,7 +3,16 @@ in-edges, q from the destination, k/v from the sources.
 
 Inside a Model the module is a parameter container: `Model.forward` composes `attn_u`, `Wvc`, `bvc`
 from its weights and runs the levelised sweep kernel.  `composed()` is that composition."""
+import torch
 import torch.nn as nn
+
+
+def segment_softmax(a, seg, n):
+    """torch_geometric.utils.softmax over segments `seg` (values 0..n-1): exp(a - max) / (sum + 1e-16)."""
+    m = torch.full((n,), float('-inf'), dtype=a.dtype, device=a.device).scatter_reduce(0, seg, a, 'amax', include_self=True)
+    e = torch.exp(a - m[seg])
+    s = torch.zeros(n, dtype=a.dtype, device=a.device).index_add(0, seg, e)
+    return e / (s[seg] + 1e-16)
 
 
 class TFMlpAggr(nn.Module):
@@ -33,6 +42,19 @@ class TFMlpAggr(nn.Module):
         w_ih = gru.weight_ih_l0
         return attn_u, w_ih @ self.msg_v.weight, w_ih @ self.msg_v.bias, gru.bias_ih_l0, gru.bias_hh_l0
 
+    def attend(self, x_src, seg, n):
+        """Messages of n destinations from gathered source rows: x_src[e] is the source row of edge e, seg[e] its
+        destination (0..n-1).  Same restatement as the sweep kernel: the q term is constant over a destination's softmax
+        segment and cancels, so the score is (Wk^T w_k).x_j (tfmlp.py:38-46)."""
+        out = self.msg_k.weight.shape[0]
+        u = self.attn_lin.weight[0, out:] @ self.msg_k.weight
+        alpha = segment_softmax(x_src @ u, seg, n)
+        v = torch.nn.functional.linear(x_src, self.msg_v.weight, self.msg_v.bias) * alpha.unsqueeze(1)
+        return torch.zeros(n, out, dtype=x_src.dtype, device=x_src.device).index_add(0, seg, v)
+
     def forward(self, x, edge_index, edge_attr=None, **kwargs):
-        raise NotImplementedError('TFMlpAggr runs as part of Model.forward (levelised sweep kernel); '
-                                  'a stand-alone edge-list call is not on the DG_AE path')
+        """Stand-alone edge-list call (tfmlp.py:31-35): [N, out] messages, zero rows for nodes without in-edges.
+        Composed from PyTorch device operators (differentiable); the train step does not come through here — inside a
+        Model the aggregation runs in the levelised sweep kernels."""
+        src, dst = edge_index[0].long(), edge_index[1].long()
+        return self.attend(x.index_select(0, src), dst, x.shape[0])
