@@ -17,6 +17,9 @@
 //   * parameter gradients leave through per-workgroup slabs and a fixed-order reduction kernel: no float atomics,
 //     bit-identical from run to run.
 #include "struct_stage_x3_common.h"
+#ifndef MGV_BWD2_D
+#define MGV_BWD2_D 2
+#endif
 
 namespace mgv {
 
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             float4 acc[2], own[2], dy[2];
             float deg[2];
             int cls[2];
-            tile_rows<H, 2, true>(a, base, grp, 32, lr, idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).idx, *idx_lds(idx_base, b).dmax(), acc, own, dy, deg, cls);
+            tile_rows<H, 2, true, MGV_BWD2_D>(a, base, grp, 32, lr, idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).idx, *idx_lds(idx_base, b).dmax(), acc, own, dy, deg, cls);
             // (0) the previous tile's P4 (last reader of the planes and of xe) is over in every wave; placed here, behind the
             //     gather, it waits where the waves wait for memory anyway
             __syncthreads();

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
             float4 acc[RPG], own[RPG], dy[RPG];
             float deg[RPG];
             int cls[RPG];
-            tile_rows<H, RPG, false>(a, base, grp, S::GROUPS, lr, idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).idx, *idx_lds(idx_base, b).dmax(), acc, own, dy, deg, cls);
+            tile_rows<H, RPG, false, (H == 64 ? 3 : 4)>(a, base, grp, S::GROUPS, lr, idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).idx, *idx_lds(idx_base, b).dmax(), acc, own, dy, deg, cls);
 #pragma unroll
             for (int rr = 0; rr < RPG; ++rr) {
                 const int row = grp + rr * S::GROUPS;

@@ -279,12 +279,12 @@ __device__ __forceinline__ void row_generic(const StageX3Args& a, int64_t node, 
     }
 }
 
-template <int H, int RPG, bool DY>
+template <int H, int RPG, bool DY, int D = 2>
 __device__ __forceinline__ void tile_rows(const StageX3Args& a, int64_t base, int grp, int groups, int lr, const int* s_ptr,
                                           const int* s_idx, int dmax, float4 (&acc)[RPG], float4 (&own)[RPG], float4 (&dy)[RPG],
                                           float (&deg)[RPG], int (&cls)[RPG]) {
     const bool two = DY && a.gy_agg != nullptr;
-    constexpr int D = (RPG >= 4 || DY) ? 2 : 4;      // RPG*D (x2 with DY) row loads in flight per lane: 8
+    // D neighbour slots per row and chunk: RPG*D (x2 with DY) row loads in flight per lane
     if (dmax < (1 << 30) && base + kTileRows <= a.N) {
         rows_chunked<H, D, RPG, DY>(a, base, grp, groups, lr, s_ptr, s_idx, dmax, two, acc, own, dy, deg, cls);
     } else {                                         // partial last tile, or an index list beyond LDS
