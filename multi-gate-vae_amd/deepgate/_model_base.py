@@ -107,7 +107,11 @@ class FunctionalModel(nn.Module):
         parts = [getattr(self, 'aggr_%s_func' % n).composed(getattr(self, 'update_%s_func' % n)) for n, _ in self.GATES]
         return [torch.stack([p[i] for p in parts]) for i in range(5)]
 
-    def forward(self, G):
+    def forward(self, G, after_hs=None):
+        """`after_hs(hs)` (optional): called once hs exists and BEFORE the level sweep is recorded; its result is left in
+        `self.after_hs_out`.  Trainer.run_batch starts the reconstruction branch there: its autograd nodes are then older than
+        the sweep's, so the backward engine enqueues the sweep backward first and the branch's backward (on its own stream)
+        runs beside it instead of beside the bandwidth-bound readout backward."""
         if self.num_rounds < 1:
             raise ValueError('num_rounds must be >= 1')
         plan = plan_of(G, [gid for _, gid in self.GATES])
@@ -120,6 +124,7 @@ class FunctionalModel(nn.Module):
         # as this event has fired, next to the (latency-bound, GPU-underfilling) level sweep
         self._hs_ready = torch.cuda.Event()
         self._hs_ready.record()
+        self.after_hs_out = after_hs(hs) if after_hs is not None else None
         hf = ops.FuncSweepFn.apply(plan, hs, *self._sweep_params())
         # further rounds (dg_ae_model_aig.py:70; the reference default and train.py use 1): every node is updated again from its
         # previous state.  Compatibility path composed from PyTorch device operators, level by level — correct, not tuned.

@@ -358,6 +358,9 @@ def gather_sum(h, nbr_ptr=None, nbr_idx=None, plan=None, reverse=False):
 # ------------------------------------------------------------------------------------------------
 # levelised functional sweep
 # ------------------------------------------------------------------------------------------------
+_SWEEP_BWD_EVENT = None
+
+
 class FuncSweepFn(torch.autograd.Function):
     """hf = sweep(hs) over levels 1..L-1 (dg_ae_model_aig.py:70-97); parameters are the per-slot
     composed tensors attn_u [T,2H], Wvc [T,3H,2H], bvc/bih/bhh [T,3H]."""
@@ -390,6 +393,12 @@ class FuncSweepFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ghf):
+        # start signal for work that should run BESIDE the (latency-bound) sweep backward on another stream: the reconstruction
+        # branch's backward waits for it (ReconLossFn.backward), instead of starting beside the bandwidth-bound readout backward
+        global _SWEEP_BWD_EVENT
+        if ghf.is_cuda:
+            _SWEEP_BWD_EVENT = torch.cuda.Event()
+            _SWEEP_BWD_EVENT.record()
         plan, par = ctx.plan, ctx.par
         hs, hf = ctx.saved_tensors
         N, H = hs.shape
@@ -500,6 +509,10 @@ class ReconLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gloss, _gc, _gp):
+        global _SWEEP_BWD_EVENT
+        if _SWEEP_BWD_EVENT is not None and gloss.is_cuda:
+            torch.cuda.current_stream().wait_event(_SWEEP_BWD_EVENT)
+            _SWEEP_BWD_EVENT = None
         std, ps, pd, ns, nd = ctx.saved_tensors
         H2 = std.shape[1]
         H = H2 // 2

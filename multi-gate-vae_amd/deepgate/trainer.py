@@ -5,6 +5,7 @@ Appendix B): gradients ARE averaged across ranks (one RCCL all-reduce of the fla
 step), only rank 0 writes checkpoints, step metrics come from four device-side counters instead of a
 host copy of every edge prediction, and the dead N x N negative mask of the edge split is never built.
 """
+import inspect
 import os
 import sys
 import time
@@ -155,31 +156,42 @@ class Trainer():
         val/test ratios only permutes the edges (preprocessing.py:41-50), to which the mean over edges is
         invariant: train_pos_edge_index is the batch's edge_index."""
         batch.train_pos_edge_index = batch.edge_index
-        hs, hf = self.model(batch)
         neg = getattr(batch, 'neg_edge_index', None)
-        keys = None
-        if neg is None and getattr(batch, '_mgv_plan', None) is None:
-            # no plan (hence no device sampler): sorted edge keys for the torch rejection sampler, static per batch
-            keys = getattr(batch, '_mgv_edge_keys', None)
-            if keys is None:
-                keys = batch._mgv_edge_keys = sorted_edge_keys(batch.edge_index, batch.num_nodes)
-        side = self._side_stream() if (self.overlap and hs.is_cuda and hasattr(self.model, '_hs_ready')) else None
-        if side is not None:
-            # reconstruction branch (hs_decompose -> decoder loss) on a second HIP stream: it runs beside the level
-            # sweep forward and, because autograd replays a node on its forward stream, beside the sweep backward
-            main = torch.cuda.current_stream()
+        dev_is_cuda = next(self.model.parameters()).is_cuda
+        if getattr(self, '_has_after_hs', None) is None:
+            self._has_after_hs = 'after_hs' in inspect.signature(self.model.forward).parameters
+        side = self._side_stream() if (self.overlap and dev_is_cuda and self._has_after_hs) else None
+
+        def recon(hs):
+            k = None
+            if neg is None and getattr(batch, '_mgv_plan', None) is None:
+                # no plan (hence no device sampler): sorted edge keys for the torch rejection sampler, static per batch
+                k = getattr(batch, '_mgv_edge_keys', None)
+                if k is None:
+                    k = batch._mgv_edge_keys = sorted_edge_keys(batch.edge_index, batch.num_nodes)
+            return self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred, edge_keys=k,
+                                         plan=getattr(batch, '_mgv_plan', None))
+
+        def recon_on_side(hs):
+            # reconstruction branch (hs_decompose -> decoder loss) on a second HIP stream, recorded BEFORE the level sweep: it
+            # runs beside the sweep forward, and its backward (replayed on this stream, enqueued after the sweep backward
+            # because its nodes are older) beside the latency-bound sweep backward
             side.wait_event(self.model._hs_ready)
             hs.record_stream(side)
             with torch.cuda.stream(side):
-                loss, pred_bin, gt_bin = self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred,
-                                                               edge_keys=keys, plan=getattr(batch, '_mgv_plan', None))
+                return recon(hs)
+
+        if side is not None:
+            hs, hf = self.model(batch, after_hs=recon_on_side)
+            loss, pred_bin, gt_bin = self.model.after_hs_out
+            main = torch.cuda.current_stream()
             main.wait_stream(side)
             for t in (loss, pred_bin, gt_bin, self.model.last_confusion):
                 if t is not None:
                     t.record_stream(main)
         else:
-            loss, pred_bin, gt_bin = self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred, edge_keys=keys,
-                                                           plan=getattr(batch, '_mgv_plan', None))
+            hs, hf = self.model(batch)
+            loss, pred_bin, gt_bin = recon(hs)
         loss_status = {'recon_loss': loss, 'pred_bin': pred_bin, 'gt_bin': gt_bin}
         if 'VAE' in getattr(self.args, 'model', '') and hasattr(self.model, 'kl_loss'):
             s_kl, t_kl = self.model.kl_loss()
