@@ -271,6 +271,8 @@ __global__ __launch_bounds__(kLT, 4) void k_level_fwd_x3(LevelX3Args a) {
     float* s_o = reinterpret_cast<float*>(smem_raw + M::o_zhi);       // output tile, after the MFMAs
     const LvlIdx ix = lvl_idx(smem_raw + M::o_idx_f);
     const int tile = a.tile_begin + blockIdx.x;
+    STAMP_DECL
+    STAMP_BEGIN;
     const int start = a.tile_start[tile], count = a.tile_count[tile], g = a.tile_slot[tile];
     stage_spans(a, start, count, ix);
     const LvlSmall sv = lvl_small<H>(a, g, reinterpret_cast<float*>(smem_raw + M::o_small_f));
@@ -278,8 +280,10 @@ __global__ __launch_bounds__(kLT, 4) void k_level_fwd_x3(LevelX3Args a) {
     const int wc = w % S::WPC, wr = w / S::WPC;
     const int grp = tid / LPR, lr = tid % LPR;
     lds_barrier();
+    STAMP(0);
     stage_in_edges(a, ix);
     lds_barrier();
+    STAMP(1);
     const float4 us = ld4(sv.u + 4 * lr), uf = ld4(sv.u + H + 4 * lr);
     {
         InRows<H> L[RPG];
@@ -300,9 +304,12 @@ __global__ __launch_bounds__(kLT, 4) void k_level_fwd_x3(LevelX3Args a) {
             if (lr == 0) sv.sa[row] = sp[i].y > sp[i].x ? 1.0f : 0.0f;
         }
     }
+    STAMP(2);
     lds_barrier();
+    STAMP(3);
     f32x4 ar[S::RTW], az[S::RTW], an[S::RTW];
     lvl_gemm_x3<H>(a.wpack + (int64_t)g * 4 * 6 * H * H, z_hi, z_lo, ar, az, an);
+    STAMP(4);
     lds_barrier();                   // s_o overlays the planes
     {
         const int col = wc * 16 + r;
@@ -321,12 +328,15 @@ __global__ __launch_bounds__(kLT, 4) void k_level_fwd_x3(LevelX3Args a) {
                 s_o[row * LDO + col] = (1.0f - zz) * nn;        // h0 = 0
             }
     }
+    STAMP(5);
     lds_barrier();
 #pragma unroll
     for (int i = 0; i < RPG; ++i) {
         const int row = grp + i * GROUPS;
         if (row < count) st4(a.hf + (int64_t)ix.node[row] * H + 4 * lr, ld4(s_o + row * LDO + 4 * lr));
     }
+    STAMP(6);
+    STAMP_FLUSH(a);
 }
 
 __device__ __forceinline__ void colsum_lds_lx(float v, float* dst) {

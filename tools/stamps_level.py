@@ -14,6 +14,8 @@ import torch  # noqa: E402
 import deepgate  # noqa: E402
 from deepgate import ops, synthetic as syn  # noqa: E402
 
+FWD = ['tile meta + spans + small vectors', 'in-edge lists', 'row gathers + attention + zbar planes', 'barrier', 'mfma (weights from L2)',
+       'gru epilogue -> LDS (+ barrier)', 'barrier + row stores']
 BWD = ['tile meta + spans + small vectors', 'edge lists + per-edge scalars', 'pull + attention rows', 'barrier',
        'recompute mfma', 'gru backward', 'write dG planes (+2 barriers)', 'dgrad mfma', '(unused)',
        'd(zbar) tile (+2 barriers)', 'attention backward + row stores', 'dG stores, lds atomics, barrier, slab store']
@@ -49,6 +51,19 @@ def main():
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     ltp = (ctypes.c_int32 * len(plan.level_tile_ptr))(*plan.level_tile_ptr)
     lib.mgv_diag_set_level_stamps(P(stamps))
+    hf2 = torch.empty_like(hf)
+    hf2.zero_()
+    rc = lib.mgv_diag_func_sweep_fwd_x3_impl(
+        H, ctypes.c_int64(N), T, plan.num_levels, ltp, P(plan.order), P(plan.order_span), P(plan.tile_start), P(plan.tile_count),
+        P(plan.tile_slot), P(plan.in_ptr), P(plan.in_src), P(hs), P(hf2), P(attn_u), P(wpack), P(bvc), P(bih), P(bhh), st)
+    torch.cuda.synchronize()
+    assert rc == 0, rc
+    t = stamps.view(8, 16).double().cpu()
+    tot = t.sum()
+    print('level forward: shares of summed wave cycles; %.0f cycles per tile per wave' % (tot / 8 / plan.num_tiles))
+    for k, name in enumerate(FWD):
+        print('   %-44s %5.1f%%' % (name, 100 * t[:, k].sum() / tot))
+    stamps.zero_()
     rc = lib.mgv_diag_func_sweep_bwd_x3_impl(
         H, ctypes.c_int64(N), T, plan.num_levels, ltp, P(plan.order), P(plan.order_span), ctypes.c_int64(plan.n_active),
         P(plan.tile_start), P(plan.tile_count), P(plan.tile_slot), P(plan.slot_tiles), stp, P(plan.in_ptr), P(plan.in_src),
