@@ -211,10 +211,12 @@ int mgv_func_loss_fwd(int H, int64_t P, const float* hf, const int64_t* pair_a, 
                       const float* tt, float eps, float* dis, double* ws, void* stream);
 /* the same gradient without atomics and without a zero-filled output: every node PULLS over the pairs it belongs to, given
  * the pair lists grouped by first member (a_ptr[N+1], a_pair[P] = pair ids) and by second member (b_ptr, b_pair) — e.g. from
- * mgv_plan_csr over (pair_a, pair_b) with its edge-id outputs; dhf[N][H] is WRITTEN for every node; bit-reproducible */
+ * mgv_plan_csr over (pair_a, pair_b) with its edge-id outputs; dhf[N][H] is WRITTEN for every node; bit-reproducible.
+ * add (nullable, [N][H]): a gradient the same rows receive from another consumer of hf (the readout, trainer.py:155-156), summed
+ * into dhf on the way out instead of by a separate N x H add */
 int mgv_func_loss_bwd_csr(int H, int64_t N, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b, const float* tt_sim,
                           const float* dis, float eps, const double* workspace8, const float* grad_loss, const int32_t* a_ptr,
-                          const int32_t* a_pair, const int32_t* b_ptr, const int32_t* b_pair, float* dhf, void* stream);
+                          const int32_t* a_pair, const int32_t* b_ptr, const int32_t* b_pair, const float* add, float* dhf, void* stream);
 int mgv_func_loss_bwd(int H, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b,
                       const float* tt, const float* dis, float eps, const double* ws, const float* gscale,
                       float* dhf, void* stream);

@@ -319,7 +319,7 @@ template <int H>
 __global__ __launch_bounds__(kThreads) void k_func_bwd_pull(int64_t N, int64_t P, const float* hf, const int64_t* pa, const int64_t* pb,
                                                             const float* tt, const float* dis, float eps, const double* ws, const float* gscale,
                                                             const int32_t* a_ptr, const int32_t* a_pair, const int32_t* b_ptr,
-                                                            const int32_t* b_pair, float* dhf) {
+                                                            const int32_t* b_pair, const float* add, float* dhf) {
     constexpr int LPR = H / 4, RPB = kThreads / LPR;
     const int lr = threadIdx.x % LPR;
     const ZStats z = zstats(ws, P);
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void k_func_bwd_pull(int64_t N, int64_t P
         const float4 own = ld4(hf + v * H + 4 * lr);
         const float oo = group_sum<LPR>(dot4(own, own));
         const float ro = sqrtf(oo), no = fmaxf(ro, eps);
-        float4 acc = zero4();
+        float4 acc = add ? ld4(add + v * H + 4 * lr) : zero4();      // gradient the same rows receive from another consumer
 #pragma unroll 1
         for (int side = 0; side < 2; ++side) {
             const int32_t* lp = side ? b_ptr : a_ptr;
@@ -516,14 +516,14 @@ extern "C" int mgv_func_loss_fwd(int H, int64_t P, const float* hf, const int64_
 
 extern "C" int mgv_func_loss_bwd_csr(int H, int64_t N, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b, const float* tt,
                                      const float* dis, float eps, const double* ws, const float* gscale, const int32_t* a_ptr,
-                                     const int32_t* a_pair, const int32_t* b_ptr, const int32_t* b_pair, float* dhf, void* stream) {
+                                     const int32_t* a_pair, const int32_t* b_ptr, const int32_t* b_pair, const float* add, float* dhf, void* stream) {
     MGV_CHECK_ARG(N >= 0 && P >= 2 && hf && pair_a && pair_b && tt && dis && ws && gscale && a_ptr && a_pair && b_ptr && b_pair && dhf);
     if (N == 0) return MGV_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (H) {
-        case 16: hipLaunchKernelGGL((mgv::k_func_bwd_pull<16>), dim3(mgv::items_grid(N, mgv::kThreads / 4)), dim3(mgv::kThreads), 0, st, N, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, a_ptr, a_pair, b_ptr, b_pair, dhf); break;
-        case 32: hipLaunchKernelGGL((mgv::k_func_bwd_pull<32>), dim3(mgv::items_grid(N, mgv::kThreads / 8)), dim3(mgv::kThreads), 0, st, N, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, a_ptr, a_pair, b_ptr, b_pair, dhf); break;
-        case 64: hipLaunchKernelGGL((mgv::k_func_bwd_pull<64>), dim3(mgv::items_grid(N, mgv::kThreads / 16)), dim3(mgv::kThreads), 0, st, N, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, a_ptr, a_pair, b_ptr, b_pair, dhf); break;
+        case 16: hipLaunchKernelGGL((mgv::k_func_bwd_pull<16>), dim3(mgv::items_grid(N, mgv::kThreads / 4)), dim3(mgv::kThreads), 0, st, N, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, a_ptr, a_pair, b_ptr, b_pair, add, dhf); break;
+        case 32: hipLaunchKernelGGL((mgv::k_func_bwd_pull<32>), dim3(mgv::items_grid(N, mgv::kThreads / 8)), dim3(mgv::kThreads), 0, st, N, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, a_ptr, a_pair, b_ptr, b_pair, add, dhf); break;
+        case 64: hipLaunchKernelGGL((mgv::k_func_bwd_pull<64>), dim3(mgv::items_grid(N, mgv::kThreads / 16)), dim3(mgv::kThreads), 0, st, N, P, hf, pair_a, pair_b, tt, dis, eps, ws, gscale, a_ptr, a_pair, b_ptr, b_pair, add, dhf); break;
         default: return MGV_EUNSUPPORTED;
     }
     MGV_LAUNCH_RET();

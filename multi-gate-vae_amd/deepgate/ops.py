@@ -587,10 +587,12 @@ def pair_lists(tt_pair_index, num_nodes):
 
 class FuncLossFn(torch.autograd.Function):
     """L1(z(1 - cos(hf[a], hf[b])), z(tt_sim)) with z = zero_normalization (trainer.py:158-163).
-    `lists` (optional, from pair_lists): backward without atomics and without a zero-filled gradient."""
+    `lists` (optional, from pair_lists): backward without atomics and without a zero-filled gradient.
+    `passthrough`: also return hf itself; a second consumer of hf (the readout) that reads THIS output hands its gradient to
+    this node's backward, whose pull kernel adds it on the way out — autograd then sees one consumer of hf and no N x H add."""
 
     @staticmethod
-    def forward(ctx, hf, tt_pair_index, tt_sim, lists=None):
+    def forward(ctx, hf, tt_pair_index, tt_sim, lists=None, passthrough=False):
         hfd = check(hf.detach().contiguous(), F32, 'hf')
         pa, pb = _edge_rows(tt_pair_index)
         tt = check(tt_sim.detach().to(F32).contiguous(), F32, 'tt_sim')
@@ -600,32 +602,49 @@ class FuncLossFn(torch.autograd.Function):
         _hip.call('mgv_func_loss_fwd', H, P, ptr(hfd), ptr(pa), ptr(pb), ptr(tt), 1e-8, ptr(dis), ptr(ws))
         ctx.save_for_backward(hfd, pa, pb, tt, dis, ws)
         ctx.lists = lists
-        return (ws[4] / P).to(F32)
+        ctx.set_materialize_grads(False)
+        loss = (ws[4] / P).to(F32)
+        if passthrough:
+            return loss, hf.view_as(hf)
+        return loss
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_pass=None):
         hfd, pa, pb, tt, dis, ws = ctx.saved_tensors
+        if g is None:                      # only the pass-through output was used
+            return g_pass, None, None, None, None
         gs = g.detach().to(F32).reshape(1).contiguous()
         if ctx.lists is not None:
             dhf = torch.empty_like(hfd)
+            add = check(g_pass.detach().contiguous(), F32, 'g_pass') if g_pass is not None else None
             _hip.call('mgv_func_loss_bwd_csr', hfd.shape[1], hfd.shape[0], pa.numel(), ptr(hfd), ptr(pa), ptr(pb), ptr(tt), ptr(dis), 1e-8,
-                      ptr(ws), ptr(gs), *[ptr(t) for t in ctx.lists], ptr(dhf))
-            return dhf, None, None, None
-        dhf = torch.zeros_like(hfd)
+                      ptr(ws), ptr(gs), *[ptr(t) for t in ctx.lists], ptr(add), ptr(dhf))
+            return dhf, None, None, None, None
+        dhf = torch.zeros_like(hfd) if g_pass is None else g_pass.detach().to(F32).clone()
         _hip.call('mgv_func_loss_bwd', hfd.shape[1], pa.numel(), ptr(hfd), ptr(pa), ptr(pb), ptr(tt), ptr(dis), 1e-8,
                   ptr(ws), ptr(gs), ptr(dhf))
-        return dhf, None, None, None
+        return dhf, None, None, None, None
 
 
-def func_loss(hf, tt_pair_index, tt_sim, cache=None):
-    """`cache`: any object that lives as long as the pairs do (the batch): the grouped pair lists are built once and kept on it."""
+def _pair_lists_for(hf, tt_pair_index, cache):
     lists = None
     if cache is not None and hf.is_cuda and tt_pair_index.shape[1] >= 2:
         lists = getattr(cache, '_mgv_pair_lists', None)
         if lists is None or lists[0].numel() != hf.shape[0] + 1 or lists[1].device != hf.device:
             lists = pair_lists(tt_pair_index, hf.shape[0])
             cache._mgv_pair_lists = lists
-    return FuncLossFn.apply(hf, tt_pair_index, tt_sim, lists)
+    return lists
+
+
+def func_loss(hf, tt_pair_index, tt_sim, cache=None):
+    """`cache`: any object that lives as long as the pairs do (the batch): the grouped pair lists are built once and kept on it."""
+    return FuncLossFn.apply(hf, tt_pair_index, tt_sim, _pair_lists_for(hf, tt_pair_index, cache))
+
+
+def func_loss_passthrough(hf, tt_pair_index, tt_sim, cache=None):
+    """(loss, hf'): hf' is hf; feed hf' to the other consumer of hf (the readout) and the two gradients meet inside the
+    function-loss backward kernel instead of in an N x H add."""
+    return FuncLossFn.apply(hf, tt_pair_index, tt_sim, _pair_lists_for(hf, tt_pair_index, cache), True)
 
 
 # ------------------------------------------------------------------------------------------------

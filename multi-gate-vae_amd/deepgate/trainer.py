@@ -196,9 +196,11 @@ class Trainer():
         if 'VAE' in getattr(self.args, 'model', '') and hasattr(self.model, 'kl_loss'):
             s_kl, t_kl = self.model.kl_loss()
             loss_status['kl_loss'] = s_kl + t_kl          # computed, not added (as in the reference)
-        prob = self.model.pred_prob(hf)
+        # hf has two consumers (trainer.py:155-163): the function loss first, the readout on the hf it passes through, so that the
+        # two gradients meet inside the function-loss backward kernel
+        loss_status['func_loss'], hf_r = ops.func_loss_passthrough(hf, batch['tt_pair_index'], batch['tt_sim'], cache=batch)
+        prob = self.model.pred_prob(hf_r)
         loss_status['prob_loss'] = self.reg_loss(prob, batch['prob'])
-        loss_status['func_loss'] = ops.func_loss(hf, batch['tt_pair_index'], batch['tt_sim'], cache=batch)
         loss_status['confusion'] = self.model.last_confusion
         return loss_status
 
