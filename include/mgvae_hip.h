@@ -100,6 +100,12 @@ int mgv_linear_x3_supported(int M, int K);
 int mgv_wpack_bf16x3(const float* W, int R, int K, int ldw, int transpose, void* hi, void* lo, void* stream);
 int mgv_linear_fwd_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
                       const void* wpack_bf16, const float* b, int M, float* Y, int ldy, void* stream);
+/* the same with residual rows: Y = [X1 | X2] W^T + b + R (R [N][ldr >= M]).  Used as the input gradient of a Linear whose input has a
+ * second consumer (hs: hs_decompose and the level sweep, dg_ae_model_aig.py:64-70,109): the other consumer's gradient rides in as R
+ * instead of meeting this one in a separate N x M add */
+int mgv_linear_fwd_x3_res(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
+                          const void* wpack_bf16, const float* b, int M, const float* R, int ldr, float* Y, int ldy,
+                          void* stream);
 int mgv_linear_wgrad_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
                         const float* dY, int lddy, int M, float* dW, float* db, void* stream);
 /* agg[i] = sum_{j in nbr(i)} h[j], deg[i] = |nbr(i)| (deg may be NULL): the scatter-add half of

@@ -16,6 +16,7 @@ struct LinX3Args {
     const __bf16* wpack;    // forward: [2][M*K] = W_hi, W_lo in fragment order (blocks (row tile, k-step))
     const float* b;
     float* Y; int ldy;
+    const float* R; int ldr;     // optional residual rows added to Y on the way out
     const float* dY; int lddy;
     float* dW; float* db;
 };
@@ -112,7 +113,11 @@ __global__ __launch_bounds__(kThreads) void k_linear_fwd_x3(LinX3Args a) {
         for (int i = tid; i < kTileRows * (M / 4); i += kThreads) {
             const int row = i / (M / 4), c4 = (i % (M / 4)) * 4;
             const int64_t node = base + row;
-            if (node < a.N) st4(a.Y + node * a.ldy + c4, ld4(s_y + row * G::LDY + c4));
+            if (node < a.N) {
+                float4 v = ld4(s_y + row * G::LDY + c4);
+                if (a.R) v = add4(v, ld4(a.R + node * a.ldr + c4));
+                st4(a.Y + node * a.ldy + c4, v);
+            }
         }
         // the planes are rewritten only after this barrier pair; s_y only after the next tile's first barrier
     }
@@ -282,20 +287,33 @@ extern "C" int mgv_linear_x3_supported(int M, int K) {
            (M == 32 && K == 32);
 }
 
-extern "C" int mgv_linear_fwd_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
-                                 const void* wpack_bf16, const float* b, int M, float* Y, int ldy, void* stream) {
+static int linear_fwd_x3_impl(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2, const void* wpack_bf16,
+                              const float* b, int M, const float* R, int ldr, float* Y, int ldy, void* stream) {
     MGV_CHECK_ARG(N >= 0 && X1 && wpack_bf16 && Y && K1 > 0 && K2 >= 0 && (K2 == 0 || X2));
     MGV_CHECK_ARG(K1 % 4 == 0 && K2 % 4 == 0 && ld1 >= K1 && ld1 % 4 == 0 && (K2 == 0 || (ld2 >= K2 && ld2 % 4 == 0)) && ldy >= M && ldy % 4 == 0);
+    MGV_CHECK_ARG(R == nullptr || (ldr >= M && ldr % 4 == 0));
     if (N == 0) return MGV_OK;
     mgv::LinX3Args a{};
     a.N = N; a.X1 = X1; a.K1 = K1; a.ld1 = ld1; a.X2 = X2; a.K2 = K2; a.ld2 = ld2; a.wpack = static_cast<const __bf16*>(wpack_bf16);
-    a.b = b; a.Y = Y; a.ldy = ldy;
+    a.b = b; a.Y = Y; a.ldy = ldy; a.R = R; a.ldr = ldr;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int K = K1 + K2;
 #define MGV_LF(MM, KK) if (M == MM && K == KK) return mgv::launch_linear_fwd_x3<MM, KK>(a, st);
     MGV_LF(64, 128) MGV_LF(128, 64) MGV_LF(64, 64) MGV_LF(64, 32) MGV_LF(32, 64) MGV_LF(32, 32)
 #undef MGV_LF
     return MGV_EUNSUPPORTED;
+}
+
+extern "C" int mgv_linear_fwd_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
+                                 const void* wpack_bf16, const float* b, int M, float* Y, int ldy, void* stream) {
+    return linear_fwd_x3_impl(N, X1, K1, ld1, X2, K2, ld2, wpack_bf16, b, M, nullptr, 0, Y, ldy, stream);
+}
+
+extern "C" int mgv_linear_fwd_x3_res(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
+                                     const void* wpack_bf16, const float* b, int M, const float* R, int ldr, float* Y, int ldy,
+                                     void* stream) {
+    MGV_CHECK_ARG(R != nullptr);
+    return linear_fwd_x3_impl(N, X1, K1, ld1, X2, K2, ld2, wpack_bf16, b, M, R, ldr, Y, ldy, stream);
 }
 
 extern "C" int mgv_linear_wgrad_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,

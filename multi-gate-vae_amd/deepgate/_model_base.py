@@ -124,22 +124,31 @@ class FunctionalModel(nn.Module):
         # as this event has fired, next to the (latency-bound, GPU-underfilling) level sweep
         self._hs_ready = torch.cuda.Event()
         self._hs_ready.record()
+        self._hs_pass = None
         self.after_hs_out = after_hs(hs) if after_hs is not None else None
-        hf = ops.FuncSweepFn.apply(plan, hs, *self._sweep_params())
+        # if the reconstruction branch ran in after_hs, hs came back through its hs_decompose node (same tensor): the sweep's
+        # gradient then reaches hs inside that Linear's input-gradient kernel instead of through a separate N x H add
+        hs_in = self._hs_pass if self._hs_pass is not None else hs
+        self._hs_pass = None
+        hf = ops.FuncSweepFn.apply(plan, hs_in, *self._sweep_params())
         # further rounds (dg_ae_model_aig.py:70; the reference default and train.py use 1): every node is updated again from its
         # previous state.  Compatibility path composed from PyTorch device operators, level by level — correct, not tuned.
         for _ in range(self.num_rounds - 1):
             mods = [(getattr(self, 'aggr_%s_func' % n), getattr(self, 'update_%s_func' % n)) for n, _ in self.GATES]
-            hf = ExtraRoundFn.apply(plan, mods, hs, hf, *[p for a, g in mods for p in _round_params(a, g)])
+            hf = ExtraRoundFn.apply(plan, mods, hs_in, hf, *[p for a, g in mods for p in _round_params(a, g)])
         return hs, hf
 
     def pred_prob(self, hf, seed=None):
         return self.readout_prob(hf, clamp01=True, seed=seed)
 
-    def recon_loss(self, hs, pos_edge_index, neg_edge_index=None, want_pred=True, edge_keys=None, plan=None):
+    def recon_loss(self, hs, pos_edge_index, neg_edge_index=None, want_pred=True, edge_keys=None, plan=None, pass_hs=False):
         """`plan` (optional): the batch's GraphPlan when pos_edge_index is the batch's own edge set (any
-        order) — the positive half of the backward then needs no atomics."""
-        st = ops.linear(hs, self.hs_decompose.weight, self.hs_decompose.bias)
+        order) — the positive half of the backward then needs no atomics.  `pass_hs`: leave hs, passed through the
+        hs_decompose node, in `self._hs_pass` for the level sweep (see forward)."""
+        if pass_hs and hs.requires_grad:
+            st, self._hs_pass = ops.linear_passthrough(hs, self.hs_decompose.weight, self.hs_decompose.bias)
+        else:
+            st = ops.linear(hs, self.hs_decompose.weight, self.hs_decompose.bias)
         if plan is not None and (plan.E != pos_edge_index.shape[1] or plan.N != hs.shape[0]):
             plan = None
         neg_csr = None

@@ -251,8 +251,9 @@ def _lin_x3(M, K):
     return _LIN_X3[key]
 
 
-def _lin_fwd(x1, x2, W, b, M, wpack=None):
-    """wpack given: W is ignored (bf16x3 path with a ready fragment-order pack)."""
+def _lin_fwd(x1, x2, W, b, M, wpack=None, res=None):
+    """wpack given: W is ignored (bf16x3 path with a ready fragment-order pack).  res [N, M]: added to the result (in the
+    kernel's store phase on the bf16x3 path)."""
     N, K1 = x1.shape
     K2 = 0 if x2 is None else x2.shape[1]
     check(x1, F32, 'x1'); check(x2, F32, 'x2'); check(b, F32, 'b')
@@ -260,14 +261,19 @@ def _lin_fwd(x1, x2, W, b, M, wpack=None):
     if wpack is not None or _lin_x3(M, K1 + K2):
         if wpack is None:
             wpack = linear_wpack(check(W, F32, 'W'))
-        _hip.call('mgv_linear_fwd_x3', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
-                  ptr(wpack), ptr(b), M, ptr(y), M)
+        if res is not None:
+            res = _rowmajor(check(res, F32, 'res'))
+            _hip.call('mgv_linear_fwd_x3_res', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
+                      ptr(wpack), ptr(b), M, ptr(res), res.stride(0), ptr(y), M)
+        else:
+            _hip.call('mgv_linear_fwd_x3', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
+                      ptr(wpack), ptr(b), M, ptr(y), M)
         return y
     check(W, F32, 'W')
     assert W.shape == (M, K1 + K2)
     _hip.call('mgv_linear_fwd', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
               ptr(W), ptr(b), M, ptr(y), M)
-    return y
+    return y if res is None else y.add_(res)
 
 
 def _rowmajor(t):
@@ -280,33 +286,39 @@ def _rowmajor(t):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = [x1 | x2] W^T + b on the MFMA row-streaming kernel (x2 optional: fuses torch.cat)."""
+    """y = [x1 | x2] W^T + b on the MFMA row-streaming kernel (x2 optional: fuses torch.cat).
+    `passthrough`: also return x1 itself; a second consumer of x1 that reads THIS output hands its gradient to this node's
+    backward, whose input-gradient kernel adds it in its store phase — autograd then sees one consumer of x1, no N x K add."""
 
     @staticmethod
-    def forward(ctx, x1, x2, W, b):
+    def forward(ctx, x1, x2, W, b, passthrough=False):
         x1d, x2d = _rowmajor(x1.detach()), _rowmajor(x2.detach()) if x2 is not None else None
         Wd = W.detach().contiguous()
         bd = b.detach().contiguous() if b is not None else None
         ctx.save_for_backward(x1d, x2d, Wd)
         ctx.has_b = b is not None
-        return _lin_fwd(x1d, x2d, Wd, bd, W.shape[0])
+        ctx.set_materialize_grads(False)
+        y = _lin_fwd(x1d, x2d, Wd, bd, W.shape[0])
+        return (y, x1.view_as(x1)) if passthrough else y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_pass=None):
         x1, x2, W = ctx.saved_tensors
+        if gy is None:                     # only the pass-through output was used
+            return g_pass, None, None, None, None
         gy = _rowmajor(gy)
         N, K1 = x1.shape
         K2 = 0 if x2 is None else x2.shape[1]
         M = W.shape[0]
         gx1 = gx2 = gW = gb = None
-        def dgrad(Ws, Kx):         # gy [N, M] x Ws [M, Kx]: the transposed weight view is packed straight from W
+        def dgrad(Ws, Kx, res=None):    # gy [N, M] x Ws [M, Kx]: the transposed weight view is packed straight from W
             if _lin_x3(Kx, M):
                 pack = torch.empty(2 * Ws.numel(), dtype=torch.bfloat16, device=W.device)
                 _pack_into(pack, 0, Ws, True)
-                return _lin_fwd(gy, None, None, None, Kx, wpack=pack)
-            return _lin_fwd(gy, None, Ws.t().contiguous(), None, Kx)
+                return _lin_fwd(gy, None, None, None, Kx, wpack=pack, res=res)
+            return _lin_fwd(gy, None, Ws.t().contiguous(), None, Kx, res=res)
         if ctx.needs_input_grad[0]:
-            gx1 = dgrad(W[:, :K1], K1)
+            gx1 = dgrad(W[:, :K1], K1, res=g_pass.detach() if g_pass is not None else None)
         if x2 is not None and ctx.needs_input_grad[1]:
             gx2 = dgrad(W[:, K1:], K2)
         if ctx.needs_input_grad[2] or (ctx.has_b and ctx.needs_input_grad[3]):
@@ -314,11 +326,16 @@ class LinearFn(torch.autograd.Function):
             gb = torch.zeros(M, dtype=F32, device=W.device) if ctx.has_b else None
             _hip.call('mgv_linear_wgrad_x3' if _lin_x3(M, K1 + K2) else 'mgv_linear_wgrad', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
                       ptr(gy), gy.stride(0), M, ptr(gW), ptr(gb))
-        return gx1, gx2, gW, gb
+        return gx1, gx2, gW, gb, None
 
 
 def linear(x, W, b=None, x2=None):
     return LinearFn.apply(x, x2, W, b)
+
+
+def linear_passthrough(x, W, b=None):
+    """(y, x'): x' is x; feed x' to the other consumer of x and its gradient is added inside this Linear's input-gradient kernel."""
+    return LinearFn.apply(x, None, W, b, True)
 
 
 class GatherSumFn(torch.autograd.Function):

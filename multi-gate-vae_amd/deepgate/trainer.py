@@ -162,7 +162,7 @@ class Trainer():
             self._has_after_hs = 'after_hs' in inspect.signature(self.model.forward).parameters
         side = self._side_stream() if (self.overlap and dev_is_cuda and self._has_after_hs) else None
 
-        def recon(hs):
+        def recon(hs, pass_hs=False):
             k = None
             if neg is None and getattr(batch, '_mgv_plan', None) is None:
                 # no plan (hence no device sampler): sorted edge keys for the torch rejection sampler, static per batch
@@ -170,7 +170,7 @@ class Trainer():
                 if k is None:
                     k = batch._mgv_edge_keys = sorted_edge_keys(batch.edge_index, batch.num_nodes)
             return self.model.recon_loss(hs, batch.train_pos_edge_index, neg, want_pred=want_pred, edge_keys=k,
-                                         plan=getattr(batch, '_mgv_plan', None))
+                                         plan=getattr(batch, '_mgv_plan', None), **({'pass_hs': True} if pass_hs else {}))
 
         def recon_on_side(hs):
             # reconstruction branch (hs_decompose -> decoder loss) on a second HIP stream, recorded BEFORE the level sweep: it
@@ -179,7 +179,7 @@ class Trainer():
             side.wait_event(self.model._hs_ready)
             hs.record_stream(side)
             with torch.cuda.stream(side):
-                return recon(hs)
+                return recon(hs, pass_hs=True)
 
         if side is not None:
             hs, hf = self.model(batch, after_hs=recon_on_side)
