@@ -77,6 +77,13 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
     float* s_dy = reinterpret_cast<float*>(smem_raw + B2::o_dy);
     f32x4* s_dhz = reinterpret_cast<f32x4*>(smem_raw + B2::o_dhz);
     const SmallVecs sv = stage_small<H>(a, reinterpret_cast<float*>(smem_raw + B2::o_small));
+    {   // b_hr, b_hz join the class rows of the LDS copy (the n gate keeps b_hn apart: it sits inside r * (...)); gradients are
+        // unaffected: they are formed from the gate gradients, not from these sums
+        __syncthreads();
+        float* xt = const_cast<float*>(sv.xtab);
+        for (int i = threadIdx.x; i < a.C * 3 * H; i += kThreadsX3) { const int c = i % (3 * H); if (c < 2 * H) xt[i] += sv.bhh[c]; }
+        __syncthreads();
+    }
     f32x4* s_part = reinterpret_cast<f32x4*>(smem_raw + B2::o_part);
     int* idx_base = reinterpret_cast<int*>(smem_raw + B2::o_idx);
     __bf16* xe_hi = reinterpret_cast<__bf16*>(smem_raw + B2::o_xe);
@@ -245,57 +252,41 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                 if (t < ne2) pf0 = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)n_idx[t >> 1] * (H * 4) + 128u * (t & 1), 0, 0);
             }
         }
-        // ---- P2. GRU forward values of row tiles 2m, 2m+1 and LayerNorm partials over this wave's 16 columns
+        // ---- P2. GRU forward values of row tiles 2m, 2m+1 and LayerNorm partials over this wave's 16 columns.  Written on 4-vectors
+        //      (two packed fp32 operations each); the r and z gates only need Wc.agg + Whh.h, so the partner's half and this wave's
+        //      half are added without asking which is which (only the n gate must tell them apart); b_hr, b_hz sit in the class table
         f32x4 vr[2], vz[2], vn[2], vg[2], vd[2];            // r, z, n, Whh_n h + b_hn, pre - (wave mean)
         float mw[2];
 #pragma unroll
         for (int il = 0; il < 2; ++il) {
             LANE_IDS
             const int row = 16 * (2 * m + il) + r;
-            f32x4 pa[3], ph[3];
-#pragma unroll
-            for (int g = 0; g < 3; ++g) {
-                const f32x4 rx = s_ex[(w * 6 + il * 3 + g) * 64 + lane];
-                pa[g] = m ? rx : oa[g][il];
-                ph[g] = m ? oa[g][il] : rx;
-            }
+            const f32x4 rx0 = s_ex[(w * 6 + il * 3 + 0) * 64 + lane], rx1 = s_ex[(w * 6 + il * 3 + 1) * 64 + lane], rx2 = s_ex[(w * 6 + il * 3 + 2) * 64 + lane];
+            const f32x4 sr = rx0 + oa[0][il], sz = rx1 + oa[1][il];
+            const f32x4 pn = m ? rx2 : oa[2][il], hn = m ? oa[2][il] : rx2;
             const float deg = sv.deg[row];
             const float* xt = sv.xtab + sv.cls[row] * 3 * H + c0;
             const bf16x4 hh = *reinterpret_cast<const bf16x4*>(hin_hi + row * LDP + c0);
             const bf16x4 hl = *reinterpret_cast<const bf16x4*>(hin_lo + row * LDP + c0);
-            const float4 bcr = ld4(sv.bc + c0), bcz = ld4(sv.bc + H + c0), bcn = ld4(sv.bc + 2 * H + c0);
-            const float4 bhr = ld4(sv.bhh + c0), bhz = ld4(sv.bhh + H + c0), bhn = ld4(sv.bhh + 2 * H + c0);
-            const float4 xr = ld4(xt), xz = ld4(xt + H), xn = ld4(xt + 2 * H);
-            const float bcr_[4] = {bcr.x, bcr.y, bcr.z, bcr.w}, bcz_[4] = {bcz.x, bcz.y, bcz.z, bcz.w}, bcn_[4] = {bcn.x, bcn.y, bcn.z, bcn.w};
-            const float bhr_[4] = {bhr.x, bhr.y, bhr.z, bhr.w}, bhz_[4] = {bhz.x, bhz.y, bhz.z, bhz.w}, bhn_[4] = {bhn.x, bhn.y, bhn.z, bhn.w};
-            const float xr_[4] = {xr.x, xr.y, xr.z, xr.w}, xz_[4] = {xz.x, xz.y, xz.z, xz.w}, xn_[4] = {xn.x, xn.y, xn.z, xn.w};
-            float s1 = 0.f;
-            f32x4 pre;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float rr = sigmoidf_(pa[0][e] + ph[0][e] + deg * bcr_[e] + xr_[e] + bhr_[e]);
-                const float zz = sigmoidf_(pa[1][e] + ph[1][e] + deg * bcz_[e] + xz_[e] + bhz_[e]);
-                const float ghn = ph[2][e] + bhn_[e];
-                const float nn = tanhf_(pa[2][e] + deg * bcn_[e] + xn_[e] + rr * ghn);
-                const float hp = (float)hh[e] + (float)hl[e];
-                pre[e] = (1.0f - zz) * nn + zz * hp;
-                vr[il][e] = rr; vz[il][e] = zz; vn[il][e] = nn; vg[il][e] = ghn;
-                s1 += pre[e];
-            }
+            const f32x4 bcr = ldv4(sv.bc + c0), bcz = ldv4(sv.bc + H + c0), bcn = ldv4(sv.bc + 2 * H + c0);
+            const f32x4 xr = ldv4(xt), xz = ldv4(xt + H), xn = ldv4(xt + 2 * H), bhn = ldv4(sv.bhh + 2 * H + c0);
+            const f32x4 rr = sigmoid4(sr + (deg * bcr + xr));
+            const f32x4 zz = sigmoid4(sz + (deg * bcz + xz));
+            const f32x4 ghn = hn + bhn;
+            const f32x4 nn = tanh4(pn + (deg * bcn + xn) + rr * ghn);
+            const f32x4 hp = f32x4{(float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]} + f32x4{(float)hl[0], (float)hl[1], (float)hl[2], (float)hl[3]};
+            const f32x4 pre = nn + zz * (hp - nn);
+            vr[il] = rr; vz[il] = zz; vn[il] = nn; vg[il] = ghn;
+            const float s1 = (pre[0] + pre[1]) + (pre[2] + pre[3]);
             if (has_ln) {
                 const float mean_w = quad_rows_sum(s1) * (1.0f / 16.0f);
-                const float4 dy = ld4(s_dy + row * LDF + c0);
-                const float4 gm = ld4(sv.lnw + c0);
-                const float dy_[4] = {dy.x, dy.y, dy.z, dy.w}, gm_[4] = {gm.x, gm.y, gm.z, gm.w};
-                float m2 = 0.f, s3 = 0.f, s4 = 0.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = pre[e] - mean_w;
-                    const float gg = dy_[e] * gm_[e];
-                    vd[il][e] = d;
-                    m2 += d * d; s3 += gg; s4 += gg * d;
-                }
-                m2 = quad_rows_sum(m2); s3 = quad_rows_sum(s3); s4 = quad_rows_sum(s4);
+                const f32x4 dy = ldv4(s_dy + row * LDF + c0), gm = ldv4(sv.lnw + c0);
+                const f32x4 d = pre - mean_w, gg = dy * gm;
+                const f32x4 dd = d * d, gd = gg * d;
+                vd[il] = d;
+                const float m2 = quad_rows_sum((dd[0] + dd[1]) + (dd[2] + dd[3]));
+                const float s3 = quad_rows_sum((gg[0] + gg[1]) + (gg[2] + gg[3]));
+                const float s4 = quad_rows_sum((gd[0] + gd[1]) + (gd[2] + gd[3]));
                 mw[il] = mean_w;
                 if (q == 0) s_part[row * 4 + wc] = f32x4{mean_w, m2, s3, s4};
             } else {
