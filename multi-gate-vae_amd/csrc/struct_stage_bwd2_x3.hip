@@ -77,13 +77,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
     float* s_dy = reinterpret_cast<float*>(smem_raw + B2::o_dy);
     f32x4* s_dhz = reinterpret_cast<f32x4*>(smem_raw + B2::o_dhz);
     const SmallVecs sv = stage_small<H>(a, reinterpret_cast<float*>(smem_raw + B2::o_small));
-    {   // b_hr, b_hz join the class rows of the LDS copy (the n gate keeps b_hn apart: it sits inside r * (...)); gradients are
-        // unaffected: they are formed from the gate gradients, not from these sums
-        __syncthreads();
-        float* xt = const_cast<float*>(sv.xtab);
-        for (int i = threadIdx.x; i < a.C * 3 * H; i += kThreadsX3) { const int c = i % (3 * H); if (c < 2 * H) xt[i] += sv.bhh[c]; }
-        __syncthreads();
-    }
+    fold_bhh_rz<H>(a, sv);
     f32x4* s_part = reinterpret_cast<f32x4*>(smem_raw + B2::o_part);
     int* idx_base = reinterpret_cast<int*>(smem_raw + B2::o_idx);
     __bf16* xe_hi = reinterpret_cast<__bf16*>(smem_raw + B2::o_xe);

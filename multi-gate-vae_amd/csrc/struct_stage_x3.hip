@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
     float* s_hin = reinterpret_cast<float*>(smem_raw + M::f_hin);
     float* s_pre = reinterpret_cast<float*>(smem_raw + M::f_pre);
     const SmallVecs sv = stage_small<H>(a, reinterpret_cast<float*>(smem_raw + M::f_small));
+    fold_bhh_rz<H>(a, sv);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wc = w % S::WPC, wr = w / S::WPC;
     const int grp = tid / S::LPR, lr = tid % S::LPR;
@@ -165,23 +166,29 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
         idx_prefetch<kThreadsF>(a, idx_lds(idx_base, b).ptr, ri);
         rp = ptr_prefetch(a, seq.at(it + 3), ntiles);
         tile_dmax(idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).dmax());
-        {
+        {   // GRU on 4-vectors (a lane's accumulator = four consecutive rows of one column): the arithmetic around the
+            // transcendentals compiles to packed fp32 operations; b_hr, b_hz sit in the LDS class table (fold_bhh_rz)
             const int col = wc * 16 + r;
-            const float bcr = sv.bc[col], bcz = sv.bc[H + col], bcn = sv.bc[2 * H + col];
-            const float bhr = sv.bhh[col], bhz = sv.bhh[H + col], bhn = sv.bhh[2 * H + col];
+            const float bcr = sv.bc[col], bcz = sv.bc[H + col], bcn = sv.bc[2 * H + col], bhn = sv.bhh[2 * H + col];
 #pragma unroll
-            for (int i = 0; i < S::RTW; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
-                    const float deg = sv.deg[row];
-                    const float* xt = sv.xtab + sv.cls[row] * 3 * H;
-                    const float rr = sigmoidf_(ar[i][e] + deg * bcr + xt[col] + bhr);
-                    const float zz = sigmoidf_(az[i][e] + deg * bcz + xt[H + col] + bhz);
-                    const float nn = tanhf_(ani[i][e] + deg * bcn + xt[2 * H + col] + rr * (anh[i][e] + bhn));
-                    const float hp = s_hin[row * S::LD + col];
-                    s_pre[row * S::LD + col] = (1.0f - zz) * nn + zz * hp;
-                }
+            for (int i = 0; i < S::RTW; ++i) {
+                const int row0 = (wr * S::RTW + i) * 16 + q * 4;
+                const f32x4 deg = ldv4(sv.deg + row0);
+                const int4 cls = *reinterpret_cast<const int4*>(sv.cls + row0);
+                const float* x0 = sv.xtab + cls.x * 3 * H + col;
+                const float* x1 = sv.xtab + cls.y * 3 * H + col;
+                const float* x2 = sv.xtab + cls.z * 3 * H + col;
+                const float* x3 = sv.xtab + cls.w * 3 * H + col;
+                const f32x4 xr = f32x4{x0[0], x1[0], x2[0], x3[0]}, xz = f32x4{x0[H], x1[H], x2[H], x3[H]}, xn = f32x4{x0[2 * H], x1[2 * H], x2[2 * H], x3[2 * H]};
+                const float* hrow = s_hin + row0 * S::LD + col;
+                const f32x4 hp = f32x4{hrow[0], hrow[S::LD], hrow[2 * S::LD], hrow[3 * S::LD]};
+                const f32x4 rr = sigmoid4(ar[i] + (deg * bcr + xr));
+                const f32x4 zz = sigmoid4(az[i] + (deg * bcz + xz));
+                const f32x4 nn = tanh4(ani[i] + (deg * bcn + xn) + rr * (anh[i] + bhn));
+                const f32x4 pre = nn + zz * (hp - nn);
+                float* prow = s_pre + row0 * S::LD + col;
+                prow[0] = pre[0]; prow[S::LD] = pre[1]; prow[2 * S::LD] = pre[2]; prow[3 * S::LD] = pre[3];
+            }
         }
         STAMP(4);
         STAMP(5);

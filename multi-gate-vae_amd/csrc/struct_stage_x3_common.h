@@ -115,6 +115,16 @@ __device__ __forceinline__ SmallVecs stage_small(const StageX3Args& a, float* ba
 }
 
 
+// b_hr, b_hz join the class rows of the LDS copy of xtab (the n gate keeps b_hn apart: it sits inside r * (...)).  Saves two adds
+// per element in the GRU; gradients are unaffected (they are formed from the gate gradients, not from these sums).
+template <int H>
+__device__ __forceinline__ void fold_bhh_rz(const StageX3Args& a, const SmallVecs& sv) {
+    __syncthreads();
+    float* xt = const_cast<float*>(sv.xtab);
+    for (int i = threadIdx.x; i < a.C * 3 * H; i += blockDim.x) { const int c = i % (3 * H); if (c < 2 * H) xt[i] += sv.bhh[c]; }
+    __syncthreads();
+}
+
 // ---- neighbour-index prefetch.  The row gathers are the only HBM-latency-bound part of the kernel, so
 // the CSR pointers and indices of tile t+1 are fetched while tile t is being computed and parked in LDS;
 // the row phase of a tile then consists of independent loads only (own rows + up to 4 neighbour rows
