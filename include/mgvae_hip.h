@@ -106,8 +106,13 @@ int mgv_linear_fwd_x3(int64_t N, const float* X1, int K1, int ld1, const float* 
 int mgv_linear_fwd_x3_res(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
                           const void* wpack_bf16, const float* b, int M, const float* R, int ldr, float* Y, int ldy,
                           void* stream);
+/* dW[M][K1+K2] += dY^T [X1 | X2], db[M] += column sums of dY (db nullable).  Deterministic: every workgroup leaves its partial in
+ * its own row of `workspace` (at least mgv_linear_wgrad_x3_ws_floats(M, K1+K2, N) floats) and a second launch adds the rows in a
+ * fixed order — no float atomics, bit-identical from call to call */
+int mgv_linear_wgrad_x3_ws_floats(int M, int K, int64_t N);
 int mgv_linear_wgrad_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
-                        const float* dY, int lddy, int M, float* dW, float* db, void* stream);
+                        const float* dY, int lddy, int M, float* dW, float* db, float* workspace, int64_t workspace_floats,
+                        void* stream);
 /* agg[i] = sum_{j in nbr(i)} h[j], deg[i] = |nbr(i)| (deg may be NULL): the scatter-add half of
  * MessagePassing.propagate as used by AggConv called on its own (gcn_conv.py:34) */
 int mgv_gather_sum(int H, int64_t N, const float* h, const int32_t* nbr_ptr, const int32_t* nbr_idx,
@@ -116,10 +121,13 @@ int mgv_gather_sum(int H, int64_t N, const float* h, const int32_t* nbr_ptr, con
 /* First half round of an encoder (digae_layer.py:260 starts every node from ones): an output row depends only on
  * the node's (degree, feature class) pair, class_id[N] numbers the pairs 0..C-1.
  * expand: out[i] = table[class_id[i]]; pull_sum: out[c] += sum over nodes of class c of
- * (gy_direct[i] + sum_{j in nbr(i)} gy_agg[j]) (gy_agg may be NULL); C * H * 4 <= 64 KiB. */
+ * (gy_direct[i] + sum_{j in nbr(i)} gy_agg[j]) (gy_agg may be NULL); C * H * 20 <= 160 KiB.  pull_sum is deterministic for
+ * C <= 8: per-workgroup rows in `workspace` (>= mgv_class_pull_sum_ws_floats(H, N, C) floats), added in a fixed order. */
 int mgv_class_expand(int H, int64_t N, const float* table, const int32_t* class_id, float* out, void* stream);
+int mgv_class_pull_sum_ws_floats(int H, int64_t N, int C);
 int mgv_class_pull_sum(int H, int64_t N, const float* gy_direct, const float* gy_agg, const int32_t* nbr_ptr,
-                       const int32_t* nbr_idx, const int32_t* class_id, int C, float* out, void* stream);
+                       const int32_t* nbr_idx, const int32_t* class_id, int C, float* out, float* workspace,
+                       int64_t workspace_floats, void* stream);
 
 /* ---- levelised functional sweep (dg_ae_model_aig.py:70-97 and mig/xag/xmg siblings; arch/tfmlp.py:38-46;
  * utils/dag_utils.py:91-105 is replaced by the tile tables).  T gate types ("slots"), per slot:
@@ -152,7 +160,8 @@ int mgv_func_sweep_bwd(int H, int64_t N, int T, int num_levels, const int32_t* l
  * `scratch` (sweep order) and one weight-gradient kernel per slot forms dWvc afterwards from the slot's tile
  * list: slot_tiles[num_tiles] = tile ids grouped by slot, slot_tile_ptr_host = HOST array [T+1] of offsets into
  * it; the small gradients (d_attn_u, dbvc, dbih, dbhh) are summed per workgroup in `scratch` too.
- * scratch_elems >= n_active * 5H + (tiles of the widest level) * T * 11H floats, n_active = length of `order`.
+ * scratch_elems >= n_active * 5H + (tiles of the widest level) * T * 11H + 256 * 6H^2 floats, n_active = length of `order`
+ * (the last term: per-workgroup rows of the weight-gradient kernel, summed in a fixed order: no float atomics at H = 64).
  * dWvc stays fp32 [T][3H][2H] and is ADDED to; ghs[N][H] is WRITTEN for every node (no zero fill needed). */
 /* hf[v] = 0 for the nodes the sweep never updates (gslot[v] == 255; dg_ae_model_aig.py:61 zero-fills the whole state):
  * with it the caller hands the sweep an UNINITIALISED hf instead of a zero-filled one */
@@ -184,7 +193,8 @@ int mgv_edge_dot_bwd(int H, int64_t E, const float* s, const float* t, int ld, c
  * (trainer.py:240-244); pred_bin[Epos+Eneg] optional */
 int mgv_recon_loss_fwd(int H, const float* s, const float* t, int ld, const int64_t* pos_src, const int64_t* pos_dst,
                        int64_t Epos, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
-                       double* sums, uint64_t* counts, int32_t* pred_bin, void* stream);
+                       double* sums, uint64_t* counts, int32_t* pred_bin, double* workspace, int64_t workspace_doubles,
+                       void* stream);
 /* ds/dt += dL/ds, dL/dt for loss = sums[0]/Epos + sums[1]/Eneg scaled by the DEVICE scalar *gscale.
  * When the positive edges are the batch graph's own edges pass its two int32 CSRs (pos_out_* by
  * source, pos_in_* by destination): the positive half then runs as gathers without atomics;
@@ -214,7 +224,8 @@ int mgv_neg_bucket(int64_t E, const int64_t* neg_src, const int64_t* neg_dst, co
  * L1 between the z-normalised dis and z-normalised tt.  ws[8] doubles (zeroed by the caller):
  * 0 sum dis, 1 sum dis^2, 2 sum tt, 3 sum tt^2, 4 sum |zd-zt| (loss = ws[4]/P), 5-6 backward sums. */
 int mgv_func_loss_fwd(int H, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b,
-                      const float* tt, float eps, float* dis, double* ws, void* stream);
+                      const float* tt, float eps, float* dis, double* ws, double* workspace, int64_t workspace_doubles,
+                      void* stream);
 /* the same gradient without atomics and without a zero-filled output: every node PULLS over the pairs it belongs to, given
  * the pair lists grouped by first member (a_ptr[N+1], a_pair[P] = pair ids) and by second member (b_ptr, b_pair) — e.g. from
  * mgv_plan_csr over (pair_a, pair_b) with its edge-id outputs; dhf[N][H] is WRITTEN for every node; bit-reproducible.
@@ -240,13 +251,18 @@ int mgv_confusion(int64_t n, const int32_t* pred_bin, const int32_t* gt_bin, uin
 
 /* ---- readout MLP pieces (arch/mlp.py:27-47 = Linear, BatchNorm1d, ReLU, Dropout; dg_ae_model_aig.py:102-106)
  * colstats: sums[c] += sum_i Y[i][c], sums[C+c] += sum_i Y[i][c]^2 (BatchNorm batch statistics) */
-int mgv_colstats(int64_t N, int C, const float* Y, int ld, double* sums, void* stream);
+/* Small sums (column statistics, loss sums, head gradients) are deterministic: every workgroup leaves its partials in its own row of
+ * `workspace` (>= mgv_sum_workspace_doubles() doubles, one buffer per stream in flight) and a second launch adds the rows in a fixed
+ * order — no floating-point atomics, bit-identical from call to call. */
+int mgv_sum_workspace_doubles(void);
+int mgv_colstats(int64_t N, int C, const float* Y, int ld, double* sums, double* workspace, int64_t workspace_doubles, void* stream);
 /* A = dropout_p(relu(gamma*(Y-mean)*invstd+beta)); dropout mask from a counter-based hash of (seed, element) */
 int mgv_bn_act_fwd(int64_t N, int C, const float* Y, const float* mean, const float* invstd, const float* gamma,
                    const float* beta, float p_drop, uint64_t seed, float* A, void* stream);
 /* dZ = dA * mask * [bn_out > 0]; sums[c] += sum dZ (= dbeta), sums[C+c] += sum dZ*xhat (= dgamma) */
 int mgv_bn_act_bwd(int64_t N, int C, const float* Y, const float* mean, const float* invstd, const float* gamma,
-                   const float* beta, float p_drop, uint64_t seed, const float* dA, float* dZ, double* sums, void* stream);
+                   const float* beta, float p_drop, uint64_t seed, const float* dA, float* dZ, double* sums, double* workspace,
+                   int64_t workspace_doubles, void* stream);
 /* dY = gamma*invstd*(dZ - [batch_stats](sums[c]/N + xhat*sums[C+c]/N)) */
 int mgv_bn_bwd_apply(int64_t N, int C, const float* Y, const float* mean, const float* invstd, const float* gamma,
                      const float* dZ, const double* sums, int batch_stats, float* dY, void* stream);
@@ -254,9 +270,10 @@ int mgv_bn_bwd_apply(int64_t N, int C, const float* Y, const float* mean, const 
 int mgv_readout_head_fwd(int64_t N, int C, const float* A, const float* w, const float* b, int clamp01, float* prob, void* stream);
 /* given dprob[N]: dA = dy w, dw += sum dy A, db += sum dy with dy = dprob * [clamp inactive] */
 int mgv_readout_head_bwd(int64_t N, int C, const float* A, const float* w, const float* b, int clamp01, const float* dprob,
-                         float* dA, float* dw, float* db, void* stream);
+                         float* dA, float* dw, float* db, double* workspace, int64_t workspace_doubles, void* stream);
 /* nn.L1Loss, reduction mean (trainer.py:71,156): sum += sum |x - target|;  dx = *gscale/n * sign(x - target) */
-int mgv_l1_loss_fwd(int64_t n, const float* x, const float* target, double* sum, void* stream);
+int mgv_l1_loss_fwd(int64_t n, const float* x, const float* target, double* sum, double* workspace, int64_t workspace_doubles,
+                    void* stream);
 int mgv_l1_loss_bwd(int64_t n, const float* x, const float* target, const float* gscale, float* dx, void* stream);
 
 /* ---- Adam on a flat fp32 buffer (torch.optim.Adam as constructed at trainer.py:73); grad is multiplied

@@ -2,6 +2,7 @@
 // transposed weight), Linear weight/bias gradient, CSR gather-sum.  HBM-bound: every row is read once
 // and written once; the small weight matrix is streamed from L2 as MFMA B fragments.
 #include "mgv_common.h"
+#include "mgv_slab.h"
 #include "../../include/mgvae_hip.h"
 
 namespace mgv {
@@ -172,9 +173,9 @@ __global__ __launch_bounds__(kThreads) void k_class_expand(int64_t N, const floa
 // would otherwise serialise: most rows of a wave share a class) and adds them to LDS once at the end
 template <int H, int CREG>
 __global__ __launch_bounds__(kThreads) void k_class_pull_sum(int64_t N, const float* gy_direct, const float* gy_agg, const int32_t* ptr,
-                                                            const int32_t* idx, const int32_t* class_id, int C, float* out) {
+                                                            const int32_t* idx, const int32_t* class_id, int C, float* slab) {
     constexpr int LPR = H / 4;
-    extern __shared__ __attribute__((aligned(16))) float s_acc[];        // [C][H]
+    extern __shared__ __attribute__((aligned(16))) float s_acc[];        // [C][H], then (CREG > 0) the per-wave stage [waves][C][H]
     float4 racc[CREG > 0 ? CREG : 1];
 #pragma unroll
     for (int c = 0; c < (CREG > 0 ? CREG : 1); ++c) racc[c] = zero4();
@@ -222,16 +223,34 @@ __global__ __launch_bounds__(kThreads) void k_class_pull_sum(int64_t N, const fl
             }
         }
     }
+    // per-workgroup result to this workgroup's slab row; the rows are added in a fixed order afterwards (mgv_slab.h)
+    float* row = slab + (int64_t)blockIdx.x * C * H;
     if (CREG > 0) {
+        // no float atomics: the lane groups of a wave meet by shuffles (fixed tree), the waves through an LDS stage in wave order
+        constexpr int NWV = kThreads / 64;
+        float* s_stage = s_acc + C * H;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
         for (int c = 0; c < CREG; ++c)
             if (c < C) {
-                float* d = s_acc + c * H + 4 * lr;
-                atomicAdd(d + 0, racc[c].x); atomicAdd(d + 1, racc[c].y); atomicAdd(d + 2, racc[c].z); atomicAdd(d + 3, racc[c].w);
+                float4 v = racc[c];
+#pragma unroll
+                for (int mk = LPR; mk < 64; mk <<= 1) {
+                    v.x += __shfl_xor(v.x, mk, 64); v.y += __shfl_xor(v.y, mk, 64); v.z += __shfl_xor(v.z, mk, 64); v.w += __shfl_xor(v.w, mk, 64);
+                }
+                if (lane < LPR) st4(s_stage + (w * C + c) * H + 4 * lane, v);
             }
+        __syncthreads();
+        for (int i = threadIdx.x; i < C * H; i += kThreads) {
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NWV; ++ww) v += s_stage[ww * C * H + i];
+            row[i] = v;
+        }
+    } else {
+        __syncthreads();
+        for (int i = threadIdx.x; i < C * H; i += kThreads) row[i] = s_acc[i];      // (LDS float atomics above: order-dependent inside a workgroup)
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < C * H; i += kThreads) atomicAdd(out + i, s_acc[i]);
 }
 
 template <int M>
@@ -325,28 +344,43 @@ extern "C" int mgv_class_expand(int H, int64_t N, const float* table, const int3
     MGV_LAUNCH_RET();
 }
 
+static int class_pull_grid(int H, int64_t N) {
+    const int rows_per_block = mgv::kThreads / (H / 4);
+    return mgv::grid_for((N + rows_per_block - 1) / rows_per_block, 8);
+}
+
+// floats of workspace mgv_class_pull_sum needs: one row of C*H partial sums per workgroup
+extern "C" int mgv_class_pull_sum_ws_floats(int H, int64_t N, int C) {
+    if (N <= 0 || C <= 0 || H <= 0) return 0;
+    return class_pull_grid(H, N) * C * H;
+}
+
 extern "C" int mgv_class_pull_sum(int H, int64_t N, const float* gy_direct, const float* gy_agg, const int32_t* nbr_ptr,
-                                  const int32_t* nbr_idx, const int32_t* class_id, int C, float* out, void* stream) {
-    MGV_CHECK_ARG(N >= 0 && gy_direct && class_id && out && C >= 1 && (int64_t)C * H * 4 <= 64 * 1024 && (!gy_agg || (nbr_ptr && nbr_idx)));
+                                  const int32_t* nbr_idx, const int32_t* class_id, int C, float* out, float* workspace,
+                                  int64_t workspace_floats, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && gy_direct && class_id && out && C >= 1 && (int64_t)C * H * 4 * 5 <= 160 * 1024 && (!gy_agg || (nbr_ptr && nbr_idx)));
     if (N == 0) return MGV_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int rows_per_block = mgv::kThreads / (H / 4);
-    const int grid = mgv::grid_for((N + rows_per_block - 1) / rows_per_block, 8);
-    const size_t shm = (size_t)C * H * sizeof(float);
+    const int grid = class_pull_grid(H, N);
+    MGV_CHECK_ARG(workspace && workspace_floats >= (int64_t)grid * C * H);
+    const size_t shm = (size_t)C * H * sizeof(float) * (C <= 8 ? 1 + mgv::kThreads / 64 : 1);
+#define MGV_CPS(HH) \
+    case HH: { \
+        if (C <= 8) { \
+            static bool set = false; \
+            if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(mgv::k_class_pull_sum<HH, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; } \
+            hipLaunchKernelGGL((mgv::k_class_pull_sum<HH, 8>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, workspace); \
+        } else { \
+            static bool set0 = false; \
+            if (!set0) { hipFuncSetAttribute(reinterpret_cast<const void*>(mgv::k_class_pull_sum<HH, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set0 = true; } \
+            hipLaunchKernelGGL((mgv::k_class_pull_sum<HH, 0>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, workspace); \
+        } \
+        break; }
     switch (H) {
-        case 16: if (C <= 8) hipLaunchKernelGGL((mgv::k_class_pull_sum<16, 8>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
-                 else hipLaunchKernelGGL((mgv::k_class_pull_sum<16, 0>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
-                 break;
-        case 32: if (C <= 8) hipLaunchKernelGGL((mgv::k_class_pull_sum<32, 8>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
-                 else hipLaunchKernelGGL((mgv::k_class_pull_sum<32, 0>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
-                 break;
-        case 64: if (C <= 8) hipLaunchKernelGGL((mgv::k_class_pull_sum<64, 8>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
-                 else hipLaunchKernelGGL((mgv::k_class_pull_sum<64, 0>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
-                 break;
-        case 128: if (C <= 8) hipLaunchKernelGGL((mgv::k_class_pull_sum<128, 8>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
-                 else hipLaunchKernelGGL((mgv::k_class_pull_sum<128, 0>), dim3(grid), dim3(mgv::kThreads), shm, st, N, gy_direct, gy_agg, nbr_ptr, nbr_idx, class_id, C, out);
-                 break;
+        MGV_CPS(16) MGV_CPS(32) MGV_CPS(64) MGV_CPS(128)
         default: return MGV_EUNSUPPORTED;
     }
+#undef MGV_CPS
+    mgv::launch_slab_sum<float, float>(workspace, grid, (int64_t)C * H, C * H, out, st);
     MGV_LAUNCH_RET();
 }

@@ -12,6 +12,7 @@
 //     rows, all of a row's loads in flight together.  8 waves per workgroup, two rows per 16-lane group.
 #include "mgv_x3.h"
 #include "mgv_stamps.h"
+#include "mgv_slab.h"
 #include <algorithm>
 #include "../../include/mgvae_hip.h"
 
@@ -24,6 +25,7 @@ constexpr int kInCap = 4;              // in-edges per row staged in LDS
 constexpr int kInRegs = 3;             // ... of which this many source rows are gathered together (longer lists continue one by one)
 constexpr int kOutCap = 16;            // out-edges per row staged in LDS
 constexpr int kOutChunk = 2;           // consumer rows in flight per lane while pulling
+constexpr int kWgradGrid = 256;         // workgroups of the deferred weight-gradient kernel (one slab row each)
 constexpr int kMaxSlots = 6;           // gate types whose attention vectors are kept in LDS
 
 struct LevelX3Args {
@@ -451,8 +453,11 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wc = w % S::WPC, wr = w / S::WPC;
     const int grp = tid / LPR, lr = tid % LPR;
+    // small parameter gradients of this tile start from ZERO in LDS: each bias column then receives exactly two addends (the two
+    // row-tile waves of its column tile; a + b == b + a bit for bit), and the workgroup's slab row is read-modified-written at
+    // the end — same result whichever wave adds first
     float* slab_small = a.wslab + ((int64_t)blockIdx.x * a.T + g) * (11 * H);
-    for (int i = tid; i < 11 * H; i += kLT) s_gu[i] = slab_small[i];
+    for (int i = tid; i < 11 * H; i += kLT) s_gu[i] = 0.f;
     lds_barrier();
     STAMP(0);
     stage_in_edges(a, ix);
@@ -598,6 +603,7 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
             const float4 zf = make_float4((float)zfh[0] + (float)zfl[0], (float)zfh[1] + (float)zfl[1], (float)zfh[2] + (float)zfl[2], (float)zfh[3] + (float)zfl[3]);
             const float ci = group_sum<LPR>(dot4(dzs, zs) + dot4(dzf, zf));
             if (row < count) attn_bwd_row<H>(a, L[i], sp[i], us, uf, dzs, dzf, ci, sv.m[row], sv.inv[row], lr, al[i], ds[i], gus, guf);
+            if (i == 0) { STAMP(12); } else { STAMP(14); }
             if (i + 1 < RPG) {
                 sp[i + 1] = ix.span[row + GROUPS];
                 L[i + 1].issue(a, ix.insrc + (row + GROUPS) * kInCap, sp[i + 1].y - sp[i + 1].x, lr);
@@ -617,6 +623,7 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
                         if (k < deg) { a.alpha[sp[i].x + k] = al[i][k]; a.dsc[sp[i].x + k] = ds[i][k]; }
                 }
             }
+            if (i == 0) { STAMP(13); }
         }
     }
     STAMP(10);
@@ -634,10 +641,32 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
                 }
             }
     }
-    atomicAdd(&s_gu[4 * lr + 0], gus.x); atomicAdd(&s_gu[4 * lr + 1], gus.y); atomicAdd(&s_gu[4 * lr + 2], gus.z); atomicAdd(&s_gu[4 * lr + 3], gus.w);
-    atomicAdd(&s_gu[H + 4 * lr + 0], guf.x); atomicAdd(&s_gu[H + 4 * lr + 1], guf.y); atomicAdd(&s_gu[H + 4 * lr + 2], guf.z); atomicAdd(&s_gu[H + 4 * lr + 3], guf.w);
-    lds_barrier();
-    for (int i = tid; i < 11 * H; i += kLT) slab_small[i] = s_gu[i];
+    // d(attention vector): the lane groups of a wave that share a column quad meet by shuffles (fixed tree), the eight waves through
+    // an LDS stage over the (now dead) zbar planes, summed in wave order — no LDS float atomics, bit-reproducible
+    {
+        constexpr int GPW = 64 / LPR;                     // lane groups per wave
+#pragma unroll
+        for (int mk = LPR; mk < 64; mk <<= 1) {
+            gus.x += __shfl_xor(gus.x, mk, 64); gus.y += __shfl_xor(gus.y, mk, 64); gus.z += __shfl_xor(gus.z, mk, 64); gus.w += __shfl_xor(gus.w, mk, 64);
+            guf.x += __shfl_xor(guf.x, mk, 64); guf.y += __shfl_xor(guf.y, mk, 64); guf.z += __shfl_xor(guf.z, mk, 64); guf.w += __shfl_xor(guf.w, mk, 64);
+        }
+        (void)GPW;
+        lds_barrier();                                   // every wave is done with the zbar planes
+        float* s_stage = reinterpret_cast<float*>(smem_raw + M::o_zhi);      // [kLW][2H]
+        if (lane < LPR) {
+            st4(s_stage + w * 2 * H + 4 * lane, gus);
+            st4(s_stage + w * 2 * H + H + 4 * lane, guf);
+        }
+        lds_barrier();
+        for (int i = tid; i < 11 * H; i += kLT) {
+            float v = s_gu[i];
+            if (i < 2 * H) {
+#pragma unroll
+                for (int ww = 0; ww < kLW; ++ww) v += s_stage[ww * 2 * H + i];
+            }
+            slab_small[i] += v;
+        }
+    }
     STAMP(11);
     STAMP_FLUSH(a);
 }
@@ -686,7 +715,7 @@ struct WgradGeom {
 template <int H>
 __global__ __launch_bounds__(WgradGeom<H>::NT) void k_sweep_wgrad_x3(const float* dgrows, const float* zrows, const int32_t* tile_list,
                                                                      int ntiles, const int32_t* tile_start, const int32_t* tile_count,
-                                                                     float* dW) {
+                                                                     float* slab) {      // [gridDim][3H * 2H] per-workgroup partials
     using G = WgradGeom<H>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __bf16* g_hi = reinterpret_cast<__bf16*>(smem_raw);
@@ -756,22 +785,29 @@ __global__ __launch_bounds__(WgradGeom<H>::NT) void k_sweep_wgrad_x3(const float
         for (int j = 0; j < G::JTW; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                atomicAdd(dW + (int64_t)((it0 + i) * 16 + q * 4 + e) * 2 * H + (jt0 + j) * 16 + r, acc[i][j][e]);
+                slab[(int64_t)blockIdx.x * (6 * H * H) + ((it0 + i) * 16 + q * 4 + e) * 2 * H + (jt0 + j) * 16 + r] = acc[i][j][e];
 }
 
-// d_attn_u, dbvc, dbih, dbhh += sums of the per-workgroup slabs; grid (T, 16): 16 adders per address
+// d_attn_u, dbvc, dbih, dbhh += sums of the per-workgroup slabs, one thread per address, slabs in index order (four
+// interleaved partial sums combined in a fixed order): deterministic
 template <int H>
 __global__ __launch_bounds__(256) void k_level_small_reduce(const float* wslab, int nslab, int T, float* d_attn_u, float* dbvc,
                                                            float* dbih, float* dbhh) {
     const int g = blockIdx.x;
-    for (int i = threadIdx.x; i < 11 * H; i += 256) {
-        float acc = 0.f;
-        for (int b = blockIdx.y; b < nslab; b += gridDim.y) acc += wslab[((int64_t)b * T + g) * (11 * H) + i];
-        float* dst = i < 2 * H ? d_attn_u + (int64_t)g * 2 * H + i
-                   : i < 5 * H ? dbvc + (int64_t)g * 3 * H + (i - 2 * H)
-                   : i < 8 * H ? dbih + (int64_t)g * 3 * H + (i - 5 * H) : dbhh + (int64_t)g * 3 * H + (i - 8 * H);
-        atomicAdd(dst, acc);
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= 11 * H) return;
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* src = wslab + (int64_t)g * (11 * H) + i;
+    int b = 0;
+    for (; b + 4 <= nslab; b += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] += src[(int64_t)(b + k) * T * (11 * H)];
     }
+    for (int k = 0; b < nslab; ++b, ++k) p[k] += src[(int64_t)b * T * (11 * H)];
+    float* dst = i < 2 * H ? d_attn_u + (int64_t)g * 2 * H + i
+               : i < 5 * H ? dbvc + (int64_t)g * 3 * H + (i - 2 * H)
+               : i < 8 * H ? dbih + (int64_t)g * 3 * H + (i - 5 * H) : dbhh + (int64_t)g * 3 * H + (i - 8 * H);
+    *dst += (p[0] + p[1]) + (p[2] + p[3]);
 }
 
 template <int H>
@@ -790,12 +826,14 @@ int launch_level_x3(bool bwd, const LevelX3Args& a, int ntiles, hipStream_t st) 
 }
 
 template <int H>
-int launch_sweep_wgrad(const LevelX3Args& a, const int32_t* tile_list, int ntiles, float* dW, hipStream_t st) {
+int launch_sweep_wgrad(const LevelX3Args& a, const int32_t* tile_list, int ntiles, float* dW, float* wgrad_slab, hipStream_t st) {
     using G = WgradGeom<H>;
     static bool set = false;
     if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_sweep_wgrad_x3<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-    hipLaunchKernelGGL(k_sweep_wgrad_x3<H>, dim3(std::min(ntiles, 256)), dim3(G::NT), G::smem_bytes, st, a.dgrows, a.zrows, tile_list, ntiles,
-                       a.tile_start, a.tile_count, dW);
+    const int grid = std::min(ntiles, kWgradGrid);
+    hipLaunchKernelGGL(k_sweep_wgrad_x3<H>, dim3(grid), dim3(G::NT), G::smem_bytes, st, a.dgrows, a.zrows, tile_list, ntiles,
+                       a.tile_start, a.tile_count, wgrad_slab);
+    launch_slab_sum<float, float>(wgrad_slab, grid, 6 * H * H, 6 * H * H, dW, st);      // fixed order: deterministic
     MGV_LAUNCH_RET();
 }
 
@@ -872,9 +910,11 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
     int nslab = 0;
     for (int lv = 1; lv < num_levels; ++lv) nslab = std::max(nslab, level_tile_ptr_host[lv + 1] - level_tile_ptr_host[lv]);
     const int64_t slab_elems = (int64_t)nslab * T * 11 * H;
+    float* wgrad_slab = nullptr;
     if (nslab > 0) {
-        MGV_CHECK_ARG(scratch && scratch_elems >= n_active * 5 * H + slab_elems && slot_tiles && slot_tile_ptr_host);
+        MGV_CHECK_ARG(scratch && scratch_elems >= n_active * 5 * H + slab_elems + (int64_t)mgv::kWgradGrid * 6 * H * H && slot_tiles && slot_tile_ptr_host);
         a.dgrows = scratch; a.zrows = scratch + n_active * 3 * H; a.wslab = a.zrows + n_active * 2 * H;
+        wgrad_slab = a.wslab + slab_elems;
         const hipError_t e = hipMemsetAsync(a.wslab, 0, slab_elems * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
@@ -893,15 +933,15 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
     }
     if (nslab > 0) {
         switch (H) {
-            case 32: hipLaunchKernelGGL(mgv::k_level_small_reduce<32>, dim3(T, 16), dim3(256), 0, st, a.wslab, nslab, T, d_attn_u, dbvc, dbih, dbhh); break;
-            case 64: hipLaunchKernelGGL(mgv::k_level_small_reduce<64>, dim3(T, 16), dim3(256), 0, st, a.wslab, nslab, T, d_attn_u, dbvc, dbih, dbhh); break;
+            case 32: hipLaunchKernelGGL(mgv::k_level_small_reduce<32>, dim3(T, (11 * 32 + 255) / 256), dim3(256), 0, st, a.wslab, nslab, T, d_attn_u, dbvc, dbih, dbhh); break;
+            case 64: hipLaunchKernelGGL(mgv::k_level_small_reduce<64>, dim3(T, (11 * 64 + 255) / 256), dim3(256), 0, st, a.wslab, nslab, T, d_attn_u, dbvc, dbih, dbhh); break;
             default: return MGV_EUNSUPPORTED;
         }
         for (int g = 0; g < T; ++g) {
             const int nt = slot_tile_ptr_host[g + 1] - slot_tile_ptr_host[g];
             if (nt <= 0) continue;
-            const int rc = H == 32 ? mgv::launch_sweep_wgrad<32>(a, slot_tiles + slot_tile_ptr_host[g], nt, dWvc + (int64_t)g * 3 * H * 2 * H, st)
-                                   : mgv::launch_sweep_wgrad<64>(a, slot_tiles + slot_tile_ptr_host[g], nt, dWvc + (int64_t)g * 3 * H * 2 * H, st);
+            const int rc = H == 32 ? mgv::launch_sweep_wgrad<32>(a, slot_tiles + slot_tile_ptr_host[g], nt, dWvc + (int64_t)g * 3 * H * 2 * H, wgrad_slab, st)
+                                   : mgv::launch_sweep_wgrad<64>(a, slot_tiles + slot_tile_ptr_host[g], nt, dWvc + (int64_t)g * 3 * H * 2 * H, wgrad_slab, st);
             if (rc != MGV_OK) return rc;
         }
     }

@@ -5,6 +5,7 @@
 // fragments in registers for the whole launch, the weight gradient reads both operands transposed from the
 // row-major planes, and the next tile's rows are in flight (registers) while the current tile is multiplied.
 #include "mgv_x3.h"
+#include "mgv_slab.h"
 #include "../../include/mgvae_hip.h"
 
 namespace mgv {
@@ -19,6 +20,7 @@ struct LinX3Args {
     const float* R; int ldr;     // optional residual rows added to Y on the way out
     const float* dY; int lddy;
     float* dW; float* db;
+    float* slab;            // weight gradient: [gridDim][M*K + M] per-workgroup partials (dW row-major, then db)
 };
 
 __device__ __forceinline__ float4 f4x(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
@@ -223,20 +225,27 @@ __global__ __launch_bounds__(64 * NW) void k_linear_wgrad_x3(LinX3Args a) {
         }
         lds_barrier();
     }
+    // per-workgroup partials to this workgroup's slab row (plain stores); k_slab_sum adds the rows in a fixed order
+    float* slab = a.slab + (int64_t)blockIdx.x * (M * K + M);
 #pragma unroll
     for (int i = 0; i < G::ITW; ++i)
 #pragma unroll
         for (int j = 0; j < G::JTW; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                atomicAdd(a.dW + (int64_t)((it0 + i) * 16 + q * 4 + e) * K + (jt0 + j) * 16 + r, acc[i][j][e]);
+                slab[((it0 + i) * 16 + q * 4 + e) * K + (jt0 + j) * 16 + r] = acc[i][j][e];
     if (a.db) {
-        if (tid < G::F4G) {              // threads beyond the dY part of a tile never load dY
-            const int c4 = (tid % (M / 4)) * 4;
-            atomicAdd(&s_db[c4 + 0], dbs.x); atomicAdd(&s_db[c4 + 1], dbs.y); atomicAdd(&s_db[c4 + 2], dbs.z); atomicAdd(&s_db[c4 + 3], dbs.w);
-        }
+        // column sums of dY: one float4 per thread into the (dead) planes, then a fixed-order sum over the threads of a column quad
+        float4* s_part = reinterpret_cast<float4*>(smem_raw);
+        if (tid < G::F4G) s_part[tid] = dbs;
         __syncthreads();
-        for (int i = tid; i < M; i += G::NT) atomicAdd(a.db + i, s_db[i]);
+        constexpr int QPR = M / 4;                       // column quads per row; thread t holds quad t % QPR
+        if (tid < M) {
+            const int c4 = tid / 4, e = tid % 4;
+            float sum = 0.f;
+            for (int t = c4; t < G::F4G && t < G::NT; t += QPR) { const float4 v = s_part[t]; sum += e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+            slab[M * K + tid] = sum;
+        }
     }
 }
 
@@ -268,7 +277,7 @@ int launch_linear_fwd_x3(const LinX3Args& a, hipStream_t st) {
 }
 
 template <int M, int K, int NW, int WI>
-int launch_linear_wgrad_x3(const LinX3Args& a, hipStream_t st) {
+int launch_linear_wgrad_x3(const LinX3Args& a, int64_t ws_floats, hipStream_t st) {
     using G = LinWgGeom<M, K, NW, WI>;
     static bool set = false;
     if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_wgrad_x3<M, K, NW, WI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
@@ -276,7 +285,11 @@ int launch_linear_wgrad_x3(const LinX3Args& a, hipStream_t st) {
     int per_cu = 160 * 1024 / G::smem_bytes;
     const int cap = 1024 / G::NT;                    // 16 waves per CU
     per_cu = per_cu > cap ? cap : per_cu;
-    hipLaunchKernelGGL((k_linear_wgrad_x3<M, K, NW, WI>), dim3(grid_for(ntiles, per_cu)), dim3(G::NT), G::smem_bytes, st, a);
+    const int grid = grid_for(ntiles, per_cu);
+    if (a.slab == nullptr || ws_floats < (int64_t)grid * (M * K + M)) return MGV_EINVAL;
+    hipLaunchKernelGGL((k_linear_wgrad_x3<M, K, NW, WI>), dim3(grid), dim3(G::NT), G::smem_bytes, st, a);
+    launch_slab_sum<float, float>(a.slab, grid, M * K + M, M * K, a.dW, st);
+    if (a.db) launch_slab_sum<float, float>(a.slab + M * K, grid, M * K + M, M, a.db, st);
     MGV_LAUNCH_RET();
 }
 
@@ -316,16 +329,24 @@ extern "C" int mgv_linear_fwd_x3_res(int64_t N, const float* X1, int K1, int ld1
     return linear_fwd_x3_impl(N, X1, K1, ld1, X2, K2, ld2, wpack_bf16, b, M, R, ldr, Y, ldy, stream);
 }
 
+// floats of workspace mgv_linear_wgrad_x3 needs: one row of M*K + M partials per workgroup (at most 4 workgroups per CU)
+extern "C" int mgv_linear_wgrad_x3_ws_floats(int M, int K, int64_t N) {
+    if (M <= 0 || K <= 0 || N < 0) return 0;
+    const int64_t ntiles = (N + mgv::kTileRows - 1) / mgv::kTileRows;
+    return mgv::grid_for(ntiles, 4) * (M * K + M);
+}
+
 extern "C" int mgv_linear_wgrad_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
-                                   const float* dY, int lddy, int M, float* dW, float* db, void* stream) {
+                                   const float* dY, int lddy, int M, float* dW, float* db, float* workspace,
+                                   int64_t workspace_floats, void* stream) {
     MGV_CHECK_ARG(N >= 0 && X1 && dY && dW && K1 > 0 && K2 >= 0 && (K2 == 0 || X2));
     MGV_CHECK_ARG(K1 % 4 == 0 && K2 % 4 == 0 && ld1 % 4 == 0 && (K2 == 0 || ld2 % 4 == 0) && lddy % 4 == 0 && lddy >= M);
     if (N == 0) return MGV_OK;
     mgv::LinX3Args a{};
-    a.N = N; a.X1 = X1; a.K1 = K1; a.ld1 = ld1; a.X2 = X2; a.K2 = K2; a.ld2 = ld2; a.dY = dY; a.lddy = lddy; a.dW = dW; a.db = db;
+    a.N = N; a.X1 = X1; a.K1 = K1; a.ld1 = ld1; a.X2 = X2; a.K2 = K2; a.ld2 = ld2; a.dY = dY; a.lddy = lddy; a.dW = dW; a.db = db; a.slab = workspace;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int K = K1 + K2;
-#define MGV_WGX(MM, KK, NW, WI) if (M == MM && K == KK) return mgv::launch_linear_wgrad_x3<MM, KK, NW, WI>(a, st);
+#define MGV_WGX(MM, KK, NW, WI) if (M == MM && K == KK) return mgv::launch_linear_wgrad_x3<MM, KK, NW, WI>(a, workspace_floats, st);
     MGV_WGX(64, 128, 8, 2) MGV_WGX(128, 64, 8, 4) MGV_WGX(64, 64, 8, 2) MGV_WGX(64, 32, 8, 4) MGV_WGX(32, 64, 8, 2) MGV_WGX(32, 32, 4, 2)
 #undef MGV_WGX
     return MGV_EUNSUPPORTED;

@@ -3,6 +3,7 @@
 // reparameterisation sampler + KL.  All HBM/gather bound: H/4 lanes read one 4H-byte row as float4s,
 // reductions go wave -> block -> one double atomic per block.
 #include "mgv_common.h"
+#include "mgv_slab.h"
 #include "../../include/mgvae_hip.h"
 
 namespace mgv {
@@ -59,6 +60,7 @@ struct ReconArgs {
     int32_t* pred_bin;          // [Ep+En] or null
     const float* gscale;        // bwd: device scalar, upstream gradient of the loss
     float* ds; float* dt;       // bwd accumulators (same ld)
+    double* slab;               // fwd: [gridDim][2] per-workgroup loss sums
 };
 
 template <int H, bool BWD>
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(kThreads) void k_recon(ReconArgs a) {
         const double c0 = block_sum_d((double)tp, red), c1 = block_sum_d((double)fp, red);
         const double c2 = block_sum_d((double)tn, red), c3 = block_sum_d((double)fn, red);
         if (threadIdx.x == 0) {
-            atomicAdd(a.sums + 0, sp); atomicAdd(a.sums + 1, sn);
+            a.slab[2 * blockIdx.x + 0] = sp; a.slab[2 * blockIdx.x + 1] = sn;      // this workgroup's row; added in a fixed order afterwards
             atomicAdd(a.cnt + 0, (unsigned long long)c0); atomicAdd(a.cnt + 1, (unsigned long long)c1);
             atomicAdd(a.cnt + 2, (unsigned long long)c2); atomicAdd(a.cnt + 3, (unsigned long long)c3);
         }
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void k_recon_bwd_rows(int64_t E, const fl
 // ws (double[8]): 0 sum d, 1 sum d^2, 2 sum t, 3 sum t^2, 4 sum |zd - zt|, 5 sum sgn, 6 sum sgn*zd
 template <int H>
 __global__ __launch_bounds__(kThreads) void k_func_dist(int64_t P, const float* hf, const int64_t* pa, const int64_t* pb,
-                                                        const float* tt, float eps, float* dis, double* ws) {
+                                                        const float* tt, float eps, float* dis, double* slab) {      // slab [gridDim][4]
     constexpr int LPR = H / 4, PPB = kThreads / LPR;
     __shared__ double red[kThreads];
     const int lr = threadIdx.x % LPR, slot = threadIdx.x / LPR;
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void k_func_dist(int64_t P, const float* 
         }
     }
     sd = block_sum_d(sd, red); sd2 = block_sum_d(sd2, red); st = block_sum_d(st, red); st2 = block_sum_d(st2, red);
-    if (threadIdx.x == 0) { atomicAdd(ws + 0, sd); atomicAdd(ws + 1, sd2); atomicAdd(ws + 2, st); atomicAdd(ws + 3, st2); }
+    if (threadIdx.x == 0) { double* row = slab + 4 * (int64_t)blockIdx.x; row[0] = sd; row[1] = sd2; row[2] = st; row[3] = st2; }
 }
 
 struct ZStats { float mu_d, inv_sd, mu_t, inv_st; };
@@ -259,7 +261,7 @@ __device__ __forceinline__ ZStats zstats(const double* ws, int64_t P) {
     return z;
 }
 
-__global__ __launch_bounds__(kThreads) void k_func_l1(int64_t P, const float* dis, const float* tt, double* ws) {
+__global__ __launch_bounds__(kThreads) void k_func_l1(int64_t P, const float* dis, const float* tt, const double* ws, double* slab) {      // slab [gridDim][3]
     __shared__ double red[kThreads];
     const ZStats z = zstats(ws, P);
     double sl = 0, ss = 0, ssz = 0;
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(kThreads) void k_func_l1(int64_t P, const float* di
         sl += fabsf(diff); ss += sg; ssz += (double)sg * zd;
     }
     sl = block_sum_d(sl, red); ss = block_sum_d(ss, red); ssz = block_sum_d(ssz, red);
-    if (threadIdx.x == 0) { atomicAdd(ws + 4, sl); atomicAdd(ws + 5, ss); atomicAdd(ws + 6, ssz); }
+    if (threadIdx.x == 0) { double* row = slab + 3 * (int64_t)blockIdx.x; row[0] = sl; row[1] = ss; row[2] = ssz; }
 }
 
 // dL/dd_q = g/(P sd) [sgn_q - mean(sgn) - zd_q * sum(sgn*zd)/(P-1)];  d = 1 - cos
@@ -448,7 +450,8 @@ extern "C" int mgv_edge_dot_bwd(int H, int64_t E, const float* s, const float* t
 
 extern "C" int mgv_recon_loss_fwd(int H, const float* s, const float* t, int ld, const int64_t* pos_src, const int64_t* pos_dst,
                                   int64_t Epos, const int64_t* neg_src, const int64_t* neg_dst, int64_t Eneg,
-                                  double* sums, uint64_t* counts, int32_t* pred_bin, void* stream) {
+                                  double* sums, uint64_t* counts, int32_t* pred_bin, double* workspace, int64_t workspace_doubles,
+                                  void* stream) {
     MGV_CHECK_ARG(s && t && sums && counts && Epos >= 0 && Eneg >= 0 && ld >= H && ld % 4 == 0);
     MGV_CHECK_ARG((Epos == 0 || (pos_src && pos_dst)) && (Eneg == 0 || (neg_src && neg_dst)));
     if (Epos + Eneg == 0) return MGV_OK;
@@ -456,7 +459,12 @@ extern "C" int mgv_recon_loss_fwd(int H, const float* s, const float* t, int ld,
     a.s = s; a.t = t; a.ld = ld; a.psrc = pos_src; a.pdst = pos_dst; a.Ep = Epos; a.nsrc = neg_src; a.ndst = neg_dst; a.En = Eneg;
     a.sums = sums; a.cnt = reinterpret_cast<unsigned long long*>(counts); a.pred_bin = pred_bin;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_recon<HH, false>), dim3(mgv::items_grid(Epos + Eneg, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st, a));
+    int grid = 0;
+    MGV_DISPATCH_H(H, grid = mgv::items_grid(Epos + Eneg, mgv::kThreads / (HH / 4)));
+    MGV_CHECK_ARG(workspace && workspace_doubles >= 2 * (int64_t)grid);
+    a.slab = workspace;
+    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_recon<HH, false>), dim3(grid), dim3(mgv::kThreads), 0, st, a));
+    mgv::launch_slab_sum<double, double>(workspace, grid, 2, 2, sums, st);
     MGV_LAUNCH_RET();
 }
 
@@ -505,12 +513,18 @@ extern "C" int mgv_recon_loss_bwd_csr(int H, int64_t N, const float* s, const fl
 }
 
 extern "C" int mgv_func_loss_fwd(int H, int64_t P, const float* hf, const int64_t* pair_a, const int64_t* pair_b,
-                                 const float* tt, float eps, float* dis, double* ws, void* stream) {
+                                 const float* tt, float eps, float* dis, double* ws, double* workspace, int64_t workspace_doubles,
+                                 void* stream) {
     MGV_CHECK_ARG(P >= 2 && hf && pair_a && pair_b && tt && dis && ws);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_func_dist<HH>), dim3(mgv::items_grid(P, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st,
-                                         P, hf, pair_a, pair_b, tt, eps, dis, ws));
-    hipLaunchKernelGGL(mgv::k_func_l1, dim3(mgv::items_grid(P, mgv::kThreads)), dim3(mgv::kThreads), 0, st, P, dis, tt, ws);
+    int g1 = 0;
+    MGV_DISPATCH_H(H, g1 = mgv::items_grid(P, mgv::kThreads / (HH / 4)));
+    const int g2 = mgv::items_grid(P, mgv::kThreads);
+    MGV_CHECK_ARG(workspace && workspace_doubles >= 4 * (int64_t)g1 && workspace_doubles >= 3 * (int64_t)g2);
+    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_func_dist<HH>), dim3(g1), dim3(mgv::kThreads), 0, st, P, hf, pair_a, pair_b, tt, eps, dis, workspace));
+    mgv::launch_slab_sum<double, double>(workspace, g1, 4, 4, ws, st);
+    hipLaunchKernelGGL(mgv::k_func_l1, dim3(g2), dim3(mgv::kThreads), 0, st, P, dis, tt, ws, workspace);
+    mgv::launch_slab_sum<double, double>(workspace, g2, 3, 3, ws + 4, st);
     MGV_LAUNCH_RET();
 }
 

@@ -2,6 +2,7 @@
 // BatchNorm1d batch statistics, BN + ReLU + Dropout, the 32->1 head with clamp and the L1 loss,
 // and their backward passes.  All streaming over [N, C] (C = dim_mlp = 32), C/4 lanes per row.
 #include "mgv_common.h"
+#include "mgv_slab.h"
 #include "../../include/mgvae_hip.h"
 
 namespace mgv {
@@ -22,7 +23,8 @@ __device__ __forceinline__ float drop_scale(uint64_t seed, int64_t elem, float p
 }
 
 // sums[c] += sum_i Y[i][c],  sums[C + c] += sum_i Y[i][c]^2   (double)
-__global__ __launch_bounds__(kThreads) void k_colstats(int64_t N, int C, const float* Y, int ld, double* sums) {
+__global__ __launch_bounds__(kThreads) void k_colstats(int64_t N, int C, const float* Y, int ld, double* slab) {     // slab [gridDim][2C]
+    double* sums = slab + (int64_t)blockIdx.x * 2 * C;
     __shared__ double red[2 * kThreads];
     const int cq = C / 4, rows = kThreads / cq;
     const int c4 = (threadIdx.x % cq) * 4, r0 = threadIdx.x / cq;
@@ -41,8 +43,8 @@ __global__ __launch_bounds__(kThreads) void k_colstats(int64_t N, int C, const f
         if (threadIdx.x < cq) {
             double a = 0, b = 0;
             for (int r = 0; r < rows; ++r) { a += red[r * cq + threadIdx.x]; b += red[kThreads + r * cq + threadIdx.x]; }
-            atomicAdd(sums + threadIdx.x * 4 + k, a);
-            atomicAdd(sums + C + threadIdx.x * 4 + k, b);
+            sums[threadIdx.x * 4 + k] = a;          // this workgroup's row; rows are added in a fixed order afterwards
+            sums[C + threadIdx.x * 4 + k] = b;
         }
     }
 }
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_act_fwd(int64_t N, int C, const
 // dZ = dA * dropout_scale * [bn_out > 0];  sums[c] += sum dZ, sums[C+c] += sum dZ * xhat
 __global__ __launch_bounds__(kThreads) void k_bn_act_bwd(int64_t N, int C, const float* Y, const float* mean, const float* invstd,
                                                          const float* gamma, const float* beta, float p, uint64_t seed,
-                                                         const float* dA, float* dZ, double* sums) {
+                                                         const float* dA, float* dZ, double* slab) {     // slab [gridDim][2C]
+    double* sums = slab + (int64_t)blockIdx.x * 2 * C;
     __shared__ double red[2 * kThreads];
     const int cq = C / 4, rows = kThreads / cq;
     const int c4 = (threadIdx.x % cq) * 4, r0 = threadIdx.x / cq;
@@ -112,8 +115,8 @@ __global__ __launch_bounds__(kThreads) void k_bn_act_bwd(int64_t N, int C, const
         if (threadIdx.x < cq) {
             double a = 0, b = 0;
             for (int r = 0; r < rows; ++r) { a += red[r * cq + threadIdx.x]; b += red[kThreads + r * cq + threadIdx.x]; }
-            atomicAdd(sums + threadIdx.x * 4 + k, a);
-            atomicAdd(sums + C + threadIdx.x * 4 + k, b);
+            sums[threadIdx.x * 4 + k] = a;          // this workgroup's row; rows are added in a fixed order afterwards
+            sums[C + threadIdx.x * 4 + k] = b;
         }
     }
 }
@@ -160,15 +163,13 @@ __global__ __launch_bounds__(kThreads) void k_bn_bwd_apply(int64_t N, int C, con
 // BWD: dy = dprob * [0 <= y <= 1]; dA = dy w; dw += sum dy A; db += sum dy
 template <bool BWD>
 __global__ __launch_bounds__(kThreads) void k_head(int64_t N, int C, const float* A, const float* w, const float* b, int clamp01,
-                                                   float* prob, const float* dprob, float* dA, float* dw, float* db) {
-    __shared__ float s_dw[kMaxC];
+                                                   float* prob, const float* dprob, float* dA, double* slab) {     // BWD: slab [gridDim][C + 1]
     const int cq = C / 4, rows = kThreads / cq;
     const int lr = threadIdx.x % cq, r0 = threadIdx.x / cq;
     const float4 wv = ld4(w + 4 * lr);
     const float bias = b[0];
     float4 dwv = zero4();
     float dbv = 0.f;
-    if (BWD && threadIdx.x < kMaxC) s_dw[threadIdx.x] = 0.f;
     const int64_t nblk = (N + rows - 1) / rows;
     for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
         const int64_t i = blk * rows + r0;
@@ -193,18 +194,30 @@ __global__ __launch_bounds__(kThreads) void k_head(int64_t N, int C, const float
         }
     }
     if (BWD) {
-        __syncthreads();
-        atomicAdd(&s_dw[4 * lr + 0], dwv.x); atomicAdd(&s_dw[4 * lr + 1], dwv.y);
-        atomicAdd(&s_dw[4 * lr + 2], dwv.z); atomicAdd(&s_dw[4 * lr + 3], dwv.w);
+        // no float atomics: rows of a wave that share a column quad meet by shuffles (fixed tree), the waves through LDS in wave
+        // order; the workgroup's C + 1 partials go to its slab row (double) and the rows are added in a fixed order afterwards
+        __shared__ float s_stage[kThreads / 64][kMaxC + 1];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (int mk = cq; mk < 64; mk <<= 1) {
+            dwv.x += __shfl_xor(dwv.x, mk, 64); dwv.y += __shfl_xor(dwv.y, mk, 64); dwv.z += __shfl_xor(dwv.z, mk, 64); dwv.w += __shfl_xor(dwv.w, mk, 64);
+        }
         dbv = wave_sum(dbv);
+        if (lane < cq) { s_stage[w][4 * lane + 0] = dwv.x; s_stage[w][4 * lane + 1] = dwv.y; s_stage[w][4 * lane + 2] = dwv.z; s_stage[w][4 * lane + 3] = dwv.w; }
+        if (lane == 0) s_stage[w][kMaxC] = dbv;
         __syncthreads();
-        if (threadIdx.x < C) atomicAdd(dw + threadIdx.x, s_dw[threadIdx.x]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(db, dbv);
+        double* row = slab + (int64_t)blockIdx.x * (C + 1);
+        if (threadIdx.x <= C) {
+            const int c = threadIdx.x < C ? threadIdx.x : kMaxC;
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < kThreads / 64; ++ww) v += s_stage[ww][c];
+            row[threadIdx.x] = (double)v;
+        }
     }
 }
 
 // nn.L1Loss (mean): sum += sum |x - t|;   dx = g/n * sign(x - t)
-__global__ __launch_bounds__(kThreads) void k_l1_fwd(int64_t n, const float* x, const float* t, double* sum) {
+__global__ __launch_bounds__(kThreads) void k_l1_fwd(int64_t n, const float* x, const float* t, double* slab) {       // slab [gridDim]
     __shared__ double red[kThreads];
     double acc = 0;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) acc += fabsf(x[i] - t[i]);
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(kThreads) void k_l1_fwd(int64_t n, const float* x, 
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = kThreads / 2; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) atomicAdd(sum, red[0]);
+    if (threadIdx.x == 0) slab[blockIdx.x] = red[0];
 }
 __global__ __launch_bounds__(kThreads) void k_l1_bwd(int64_t n, const float* x, const float* t, const float* gscale, float* dx) {
     const float g = (*gscale) / (float)n;
@@ -227,12 +240,20 @@ inline bool c_ok(int C) { return C == 4 || C == 8 || C == 16 || C == 32 || C == 
 
 }  // namespace mgv
 
-extern "C" int mgv_colstats(int64_t N, int C, const float* Y, int ld, double* sums, void* stream) {
+// doubles of workspace the small-sum launchers need (mgv_colstats, mgv_bn_act_bwd, mgv_readout_head_bwd, mgv_l1_loss_fwd,
+// mgv_recon_loss_fwd, mgv_func_loss_fwd): one row of partials per workgroup, added in a fixed order by a second launch
+extern "C" int mgv_sum_workspace_doubles(void) { return mgv::kSumRows * mgv::kSumStride; }
+
+extern "C" int mgv_colstats(int64_t N, int C, const float* Y, int ld, double* sums, double* workspace, int64_t workspace_doubles,
+                            void* stream) {
     MGV_CHECK_ARG(N >= 0 && mgv::c_ok(C) && Y && sums && ld >= C && ld % 4 == 0);
     if (N == 0) return MGV_OK;
     const int rows = mgv::kThreads / (C / 4);
-    hipLaunchKernelGGL(mgv::k_colstats, dim3(mgv::grid_for((N + rows - 1) / rows, 8)), dim3(mgv::kThreads), 0,
-                       static_cast<hipStream_t>(stream), N, C, Y, ld, sums);
+    const int grid = mgv::grid_for((N + rows - 1) / rows, 8);
+    MGV_CHECK_ARG(workspace && workspace_doubles >= (int64_t)grid * 2 * C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mgv::k_colstats, dim3(grid), dim3(mgv::kThreads), 0, st, N, C, Y, ld, workspace);
+    mgv::launch_slab_sum<double, double>(workspace, grid, 2 * C, 2 * C, sums, st);
     MGV_LAUNCH_RET();
 }
 
@@ -246,12 +267,16 @@ extern "C" int mgv_bn_act_fwd(int64_t N, int C, const float* Y, const float* mea
 }
 
 extern "C" int mgv_bn_act_bwd(int64_t N, int C, const float* Y, const float* mean, const float* invstd, const float* gamma,
-                              const float* beta, float p_drop, uint64_t seed, const float* dA, float* dZ, double* sums, void* stream) {
+                              const float* beta, float p_drop, uint64_t seed, const float* dA, float* dZ, double* sums,
+                              double* workspace, int64_t workspace_doubles, void* stream) {
     MGV_CHECK_ARG(N >= 0 && mgv::c_ok(C) && Y && mean && invstd && gamma && beta && dA && dZ && sums);
     if (N == 0) return MGV_OK;
     const int rows = mgv::kThreads / (C / 4);
-    hipLaunchKernelGGL(mgv::k_bn_act_bwd, dim3(mgv::grid_for((N + rows - 1) / rows, 8)), dim3(mgv::kThreads), 0,
-                       static_cast<hipStream_t>(stream), N, C, Y, mean, invstd, gamma, beta, p_drop, seed, dA, dZ, sums);
+    const int grid = mgv::grid_for((N + rows - 1) / rows, 8);
+    MGV_CHECK_ARG(workspace && workspace_doubles >= (int64_t)grid * 2 * C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mgv::k_bn_act_bwd, dim3(grid), dim3(mgv::kThreads), 0, st, N, C, Y, mean, invstd, gamma, beta, p_drop, seed, dA, dZ, workspace);
+    mgv::launch_slab_sum<double, double>(workspace, grid, 2 * C, 2 * C, sums, st);
     MGV_LAUNCH_RET();
 }
 
@@ -269,25 +294,34 @@ extern "C" int mgv_readout_head_fwd(int64_t N, int C, const float* A, const floa
     if (N == 0) return MGV_OK;
     const int rows = mgv::kThreads / (C / 4);
     hipLaunchKernelGGL((mgv::k_head<false>), dim3(mgv::grid_for((N + rows - 1) / rows, 8)), dim3(mgv::kThreads), 0,
-                       static_cast<hipStream_t>(stream), N, C, A, w, b, clamp01, prob, nullptr, nullptr, nullptr, nullptr);
+                       static_cast<hipStream_t>(stream), N, C, A, w, b, clamp01, prob, nullptr, nullptr, nullptr);
     MGV_LAUNCH_RET();
 }
 
 extern "C" int mgv_readout_head_bwd(int64_t N, int C, const float* A, const float* w, const float* b, int clamp01, const float* dprob,
-                                    float* dA, float* dw, float* db, void* stream) {
+                                    float* dA, float* dw, float* db, double* workspace, int64_t workspace_doubles, void* stream) {
     MGV_CHECK_ARG(N >= 0 && mgv::c_ok(C) && A && w && b && dprob && dA && dw && db);
     if (N == 0) return MGV_OK;
     const int rows = mgv::kThreads / (C / 4);
-    hipLaunchKernelGGL((mgv::k_head<true>), dim3(mgv::grid_for((N + rows - 1) / rows, 8)), dim3(mgv::kThreads), 0,
-                       static_cast<hipStream_t>(stream), N, C, A, w, b, clamp01, nullptr, dprob, dA, dw, db);
+    const int grid = mgv::grid_for((N + rows - 1) / rows, 8);
+    MGV_CHECK_ARG(workspace && workspace_doubles >= (int64_t)grid * (C + 1));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL((mgv::k_head<true>), dim3(grid), dim3(mgv::kThreads), 0, st, N, C, A, w, b, clamp01, nullptr, dprob, dA, workspace);
+    mgv::launch_slab_sum<double, float>(workspace, grid, C + 1, C, dw, st);
+    mgv::launch_slab_sum<double, float>(workspace + C, grid, C + 1, 1, db, st);
     MGV_LAUNCH_RET();
 }
 
-extern "C" int mgv_l1_loss_fwd(int64_t n, const float* x, const float* target, double* sum, void* stream) {
+extern "C" int mgv_l1_loss_fwd(int64_t n, const float* x, const float* target, double* sum, double* workspace,
+                               int64_t workspace_doubles, void* stream) {
     MGV_CHECK_ARG(n >= 0 && sum);
     if (n == 0) return MGV_OK;
     MGV_CHECK_ARG(x && target);
-    hipLaunchKernelGGL(mgv::k_l1_fwd, dim3(mgv::ew_grid(n)), dim3(mgv::kThreads), 0, static_cast<hipStream_t>(stream), n, x, target, sum);
+    const int grid = mgv::ew_grid(n);
+    MGV_CHECK_ARG(workspace && workspace_doubles >= grid);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mgv::k_l1_fwd, dim3(grid), dim3(mgv::kThreads), 0, st, n, x, target, workspace);
+    mgv::launch_slab_sum<double, double>(workspace, grid, 1, 1, sum, st);
     MGV_LAUNCH_RET();
 }
 

@@ -156,6 +156,13 @@ class FunctionalModel(nn.Module):
             # with the batch's plan: fused device sampler, pairs bucketed for an atomic-free backward
             neg_edge_index = negative_sampling_device(plan) if plan is not None and hs.is_cuda and hs.shape[0] >= 2 and DEVICE_SAMPLER \
                 else negative_sampling(pos_edge_index, hs.shape[0], keys=edge_keys)
+        if plan is not None and hs.is_cuda and torch.is_tensor(neg_edge_index) and neg_edge_index.shape[1] > 0:
+            # given negatives: bucket them once (cached on the tensor's identity) so that their gradient needs no atomics either
+            cache = getattr(self, '_neg_cache', None)
+            if cache is None or cache[0] is not neg_edge_index:
+                from .sampling import bucket_negatives
+                cache = self._neg_cache = (neg_edge_index, bucket_negatives(neg_edge_index.long(), hs.shape[0]))
+            neg_edge_index = cache[1]
         if isinstance(neg_edge_index, NegativeEdges):
             neg_csr, neg_edge_index = neg_edge_index.csr, neg_edge_index.edge_index
         loss, counts, pred_bin = ops.ReconLossFn.apply(st, pos_edge_index, neg_edge_index, want_pred, plan, neg_csr)

@@ -111,14 +111,32 @@ STAGE_BWD = os.environ.get('MGV_STAGE_BWD', '2')
 _WS = {}
 
 
+
+
+
+def workspace(nfloats, device, dtype=F32):
+    """Scratch for the deterministic cross-workgroup sums (per-workgroup partial rows, csrc/mgv_slab.h): one growing buffer
+    per (device, stream, dtype); launches on a stream are ordered, so consecutive users may share it."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == 'cuda' else 0, dtype)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nfloats:
+        buf = _WS[key] = torch.empty(max(int(nfloats), 1), dtype=dtype, device=device)
+    return buf
+
+
+def sum_ws(device):
+    """Double workspace of the small-sum launchers (mgv_sum_workspace_doubles), per (device, stream)."""
+    return workspace(_hip.call_value('mgv_sum_workspace_doubles'), device, torch.float64)
+
+
+def _sw(device):
+    ws = sum_ws(device)
+    return ptr(ws), ws.numel()
+
+
 def _stage_ws(H, N, device):
     """Scratch slab of mgv_struct_stage_bwd2_x3 (one per device, grown on demand; contents are never read across calls)."""
-    n = _hip.call_value('mgv_struct_stage_bwd2_ws_floats', H, N)
-    ws = _WS.get(device)
-    if ws is None or ws.numel() < n:
-        ws = torch.empty(max(n, 1), dtype=F32, device=device)
-        _WS[device] = ws
-    return ws
+    return workspace(_hip.call_value('mgv_struct_stage_bwd2_ws_floats', H, N), device)
 
 
 def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, gy_direct, gy_agg,
@@ -222,7 +240,8 @@ class StructEncoderFn(torch.autograd.Function):
                     cid, C, tp, ti, tx = ctx.first
                     H = g_direct.shape[1]
                     gsum = torch.zeros(C, H, dtype=F32, device=g_direct.device)
-                    _hip.call('mgv_class_pull_sum', H, plan.N, ptr(g_direct), ptr(g_agg), ptr(p), ptr(i), ptr(cid), C, ptr(gsum))
+                    ws = workspace(_hip.call_value('mgv_class_pull_sum_ws_floats', H, plan.N, C), g_direct.device)
+                    _hip.call('mgv_class_pull_sum', H, plan.N, ptr(g_direct), ptr(g_agg), ptr(p), ptr(i), ptr(cid), C, ptr(gsum), ptr(ws), ws.numel())
                     struct_stage_bwd(torch.ones(C, H, dtype=F32, device=g_direct.device), tp, ti, tx, w[0], w[1], w[2], w[3], w[4],
                                      lw, lb, gsum, None, g, need_input_grad=False, wpack=ctx.packs[0])
                 else:
@@ -324,8 +343,13 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[2] or (ctx.has_b and ctx.needs_input_grad[3]):
             gW = torch.zeros_like(W)
             gb = torch.zeros(M, dtype=F32, device=W.device) if ctx.has_b else None
-            _hip.call('mgv_linear_wgrad_x3' if _lin_x3(M, K1 + K2) else 'mgv_linear_wgrad', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
-                      ptr(gy), gy.stride(0), M, ptr(gW), ptr(gb))
+            if _lin_x3(M, K1 + K2):
+                ws = workspace(_hip.call_value('mgv_linear_wgrad_x3_ws_floats', M, K1 + K2, N), W.device)
+                _hip.call('mgv_linear_wgrad_x3', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
+                          ptr(gy), gy.stride(0), M, ptr(gW), ptr(gb), ptr(ws), ws.numel())
+            else:
+                _hip.call('mgv_linear_wgrad', N, ptr(x1), K1, x1.stride(0), ptr(x2), K2, 0 if x2 is None else x2.stride(0),
+                          ptr(gy), gy.stride(0), M, ptr(gW), ptr(gb))
         return gx1, gx2, gW, gb, None
 
 
@@ -430,7 +454,8 @@ class FuncSweepFn(torch.autograd.Function):
         if ctx.wpack is not None:
             ltp = plan.level_tile_ptr
             widest = max([ltp[i + 1] - ltp[i] for i in range(1, len(ltp) - 1)] + [1])
-            scratch = torch.empty(plan.n_active * 5 * H + widest * T * 11 * H, dtype=F32, device=dev)
+            # rows for the deferred weight gradient, small-gradient slabs of the widest level, 256 rows of weight-gradient partials
+            scratch = torch.empty(plan.n_active * 5 * H + widest * T * 11 * H + 256 * 6 * H * H, dtype=F32, device=dev)
             stp = (_hip.ctypes.c_int32 * len(plan.slot_tile_ptr))(*plan.slot_tile_ptr)
             _hip.call('mgv_func_sweep_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.order_span),
                       plan.n_active, ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.slot_tiles), stp,
@@ -514,7 +539,7 @@ class ReconLossFn(torch.autograd.Function):
         pred = torch.empty(Ep + En, dtype=torch.int32, device=dev) if want_pred else None
         t_view = std[:, H:]
         _hip.call('mgv_recon_loss_fwd', H, ptr(std), ptr(t_view), H2, ptr(ps), ptr(pd), Ep, ptr(ns), ptr(nd), En,
-                  ptr(sums), ptr(counts), ptr(pred))
+                  ptr(sums), ptr(counts), ptr(pred), *_sw(std.device))
         loss = (sums[0] / max(Ep, 1) + sums[1] / max(En, 1)).to(F32)
         ctx.save_for_backward(std, ps, pd, ns, nd)
         ctx.plan, ctx.neg_csr = plan, neg_csr
@@ -568,7 +593,7 @@ class L1LossFn(torch.autograd.Function):
         td = check(target.detach().contiguous(), F32, 'target')
         assert xd.numel() == td.numel()
         s = torch.zeros(1, dtype=torch.float64, device=xd.device)
-        _hip.call('mgv_l1_loss_fwd', xd.numel(), ptr(xd), ptr(td), ptr(s))
+        _hip.call('mgv_l1_loss_fwd', xd.numel(), ptr(xd), ptr(td), ptr(s), *_sw(xd.device))
         ctx.save_for_backward(xd, td)
         return (s[0] / max(xd.numel(), 1)).to(F32)
 
@@ -616,7 +641,7 @@ class FuncLossFn(torch.autograd.Function):
         P, H = pa.numel(), hfd.shape[1]
         dis = torch.empty(P, dtype=F32, device=hfd.device)
         ws = torch.zeros(8, dtype=torch.float64, device=hfd.device)
-        _hip.call('mgv_func_loss_fwd', H, P, ptr(hfd), ptr(pa), ptr(pb), ptr(tt), 1e-8, ptr(dis), ptr(ws))
+        _hip.call('mgv_func_loss_fwd', H, P, ptr(hfd), ptr(pa), ptr(pb), ptr(tt), 1e-8, ptr(dis), ptr(ws), *_sw(hfd.device))
         ctx.save_for_backward(hfd, pa, pb, tt, dis, ws)
         ctx.lists = lists
         ctx.set_materialize_grads(False)
@@ -679,7 +704,7 @@ class BnReluDropFn(torch.autograd.Function):
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         if training:
             sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
-            _hip.call('mgv_colstats', N, C, ptr(yd), C, ptr(sums))
+            _hip.call('mgv_colstats', N, C, ptr(yd), C, ptr(sums), *_sw(yd.device))
             mean64 = sums[:C] / N
             var64 = (sums[C:] / N - mean64 * mean64).clamp_min(0.0)
             mean, var = mean64.to(F32), var64.to(F32)
@@ -705,7 +730,7 @@ class BnReluDropFn(torch.autograd.Function):
         ga = check(ga.contiguous(), F32, 'ga')
         dz = torch.empty_like(yd)
         sums = torch.zeros(2 * C, dtype=torch.float64, device=yd.device)
-        _hip.call('mgv_bn_act_bwd', N, C, ptr(yd), ptr(mean), ptr(invstd), ptr(g), ptr(b), p, seed, ptr(ga), ptr(dz), ptr(sums))
+        _hip.call('mgv_bn_act_bwd', N, C, ptr(yd), ptr(mean), ptr(invstd), ptr(g), ptr(b), p, seed, ptr(ga), ptr(dz), ptr(sums), *_sw(yd.device))
         dy = torch.empty_like(yd)
         _hip.call('mgv_bn_bwd_apply', N, C, ptr(yd), ptr(mean), ptr(invstd), ptr(g), ptr(dz), ptr(sums), int(training), ptr(dy))
         return dy, sums[C:].to(F32), sums[:C].to(F32), None, None, None, None, None, None, None
@@ -733,7 +758,7 @@ class HeadFn(torch.autograd.Function):
         da = torch.empty_like(ad)
         dw = torch.zeros_like(wd)
         db = torch.zeros_like(bd)
-        _hip.call('mgv_readout_head_bwd', N, C, ptr(ad), ptr(wd), ptr(bd), ctx.clamp01, ptr(gp), ptr(da), ptr(dw), ptr(db))
+        _hip.call('mgv_readout_head_bwd', N, C, ptr(ad), ptr(wd), ptr(bd), ctx.clamp01, ptr(gp), ptr(da), ptr(dw), ptr(db), *_sw(ad.device))
         return da, dw.reshape(ctx.wshape), db, None
 
 

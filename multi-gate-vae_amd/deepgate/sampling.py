@@ -28,6 +28,27 @@ class NegativeEdges:
         return self.out_ptr, self.out_dst, self.in_ptr, self.in_src
 
 
+def bucket_negatives(neg, N):
+    """NegativeEdges over the pairs `neg` [2, E] (int64, device): both CSRs from the batch builder's CSR kernels (histogram,
+    scan, cursor fill, per-list sort by pair id: every list comes out in pair order whatever order the atomics ran in), the pair
+    list re-emitted in by-source order.  Deterministic, unlike a plain atomic-cursor bucketing."""
+    dev = neg.device
+    E = int(neg.shape[1])
+    i32 = dict(dtype=torch.int32, device=dev)
+    src, dst = neg[0].contiguous(), neg[1].contiguous()
+    in_ptr, out_ptr = torch.empty(N + 1, **i32), torch.empty(N + 1, **i32)
+    in_src, in_dst, out_dst, out_slot = (torch.empty(max(E, 1), **i32) for _ in range(4))
+    n_s = _hip.call_value('mgv_plan_csr_scratch_ints', N, E)
+    scratch = torch.empty(n_s, **i32)
+    status = torch.empty(2, **i32)
+    _hip.call('mgv_plan_csr', N, E, ptr(src), ptr(dst), ptr(in_ptr), ptr(in_src), ptr(in_dst), ptr(out_ptr), ptr(out_dst), ptr(out_slot),
+              None, None, ptr(scratch), n_s, ptr(status))
+    counts = (out_ptr[1:] - out_ptr[:-1]).long()
+    srt_src = torch.repeat_interleave(torch.arange(N, device=dev), counts, output_size=E)
+    srt = torch.stack([srt_src, out_dst[:E].long()])
+    return NegativeEdges(srt, out_ptr, out_dst, in_ptr, in_src)
+
+
 def negative_sampling_device(plan, num_neg_samples=None, generator=None):
     """Same distribution as `negative_sampling` (uniform over non-edges that are not self loops, with replacement),
     drawn by one kernel from a counter-based generator seeded from torch's seed and a call counter (no host sync)."""
@@ -42,15 +63,7 @@ def negative_sampling_device(plan, num_neg_samples=None, generator=None):
     scratch = torch.zeros(4, N, dtype=torch.int32, device=dev)          # counts by source / destination, bucket cursors
     neg = torch.empty(2, E, dtype=torch.int64, device=dev)
     _hip.call('mgv_neg_sample', N, E, seed, ptr(plan.out_ptr), ptr(plan.out_dst), ptr(neg[0]), ptr(neg[1]), ptr(scratch[0]), ptr(scratch[1]))
-    ptrs = torch.zeros(2, N + 1, dtype=torch.int32, device=dev)
-    for k in range(2):                 # 1-D scans (the device-wide scan; the batched innermost-dim kernel is ~100x slower here)
-        ptrs[k, 1:] = torch.cumsum(scratch[k], 0, dtype=torch.int32)
-    srt = torch.empty(2, E, dtype=torch.int64, device=dev)
-    out_dst = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-    in_src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-    _hip.call('mgv_neg_bucket', E, ptr(neg[0]), ptr(neg[1]), ptr(ptrs[0]), ptr(ptrs[1]), ptr(scratch[2]), ptr(scratch[3]),
-              ptr(srt[0]), ptr(srt[1]), ptr(out_dst), ptr(in_src))
-    return NegativeEdges(srt, ptrs[0], out_dst, ptrs[1], in_src)
+    return bucket_negatives(neg, N)
 
 
 def sorted_edge_keys(pos_edge_index, num_nodes):

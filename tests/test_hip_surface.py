@@ -191,3 +191,35 @@ def test_train_entry_and_feature_extraction(tmp_path, monkeypatch):
         hs, hf = model(deepgate.CircuitBatch.from_arrays(syn.collate([g]), device=dev))
     np.testing.assert_allclose(emb['graph0/hs'], hs.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(emb['graph0/hf'], hf.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_two_identical_steps_give_bit_identical_gradients():
+    """Same parameters, same batch, same negatives, twice: every parameter gradient is bit-identical (no float atomics on the
+    H = 64 path: per-workgroup slabs and fixed-order reductions)."""
+    dev = _dev()
+    import types
+    import deepgate
+    from deepgate import synthetic as syn
+    torch.manual_seed(11)
+    enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=64, s_rounds=2, t_rounds=2, layernorm=True)
+    model = deepgate.dg_ae_model_aig.Model(struct_encoder=enc, dim_hidden=64).to(dev).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    arrays = syn.collate([syn.make_graph('aig', 4096, 30, 900 + i, n_inputs=256) for i in range(4)])
+    batch = deepgate.CircuitBatch.from_arrays(arrays, device=dev)
+    N = arrays['num_nodes']
+    g = torch.Generator().manual_seed(3)
+    E = arrays['edge_index'].shape[1]
+    batch.neg_edge_index = torch.stack([torch.randint(0, N, (E + N,), generator=g), torch.randint(0, N, (E + N,), generator=g)]).to(dev)
+    tr = deepgate.Trainer(types.SimpleNamespace(model='DG_AE'), model, training_id='det', save_dir='/tmp/mgv_test_exp', lr=1e-4,
+                          rc_prob_func_weight=[1.0, 4.0, 4.0], device='cuda:0', batch_size=4, distributed=False)
+    grads = []
+    for _ in range(2):
+        tr.optimizer.zero_grad()
+        ls = tr.run_batch(batch, want_pred=False)
+        tr.weighted_loss(ls).backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    diff = [k for k in grads[0] if not torch.equal(grads[0][k], grads[1][k])]
+    assert not diff, diff

@@ -38,8 +38,11 @@ def main():
     def ev():
         return torch.cuda.Event(enable_timing=True)
 
+    from deepgate import _hip
     tf = tb = 0.0
+    kf, kb = [], []
     for it in range(iters + 1):
+        _hip.profile(True)
         e0, e1, e2 = ev(), ev(), ev()
         e0.record()
         hf = ops.FuncSweepFn.apply(plan, hs, attn_u, Wvc, bvc, bih, bhh)
@@ -47,11 +50,14 @@ def main():
         hf.backward(g)
         e2.record()
         torch.cuda.synchronize()
+        table = _hip.profile(False)
         if it > 0:
             tf += e0.elapsed_time(e1)
             tb += e1.elapsed_time(e2)
-    print('N=%d levels=%d tiles=%d: sweep forward %.3f ms, backward %.3f ms (checksum %.6e)'
-          % (N, plan.num_levels, plan.num_tiles, tf / iters, tb / iters, float(hf.double().sum())))
+            kf += _hip.profile_times(table, 'mgv_func_sweep_fwd_x3')
+            kb += _hip.profile_times(table, 'mgv_func_sweep_bwd_x3')
+    print('N=%d levels=%d tiles=%d: sweep forward %.3f ms, backward %.3f ms; launcher calls alone: forward %.3f ms (min %.3f), backward %.3f ms (min %.3f)'
+          % (N, plan.num_levels, plan.num_tiles, tf / iters, tb / iters, sum(kf) / len(kf), min(kf), sum(kb) / len(kb), min(kb)))
 
 
 if __name__ == '__main__':

@@ -18,7 +18,8 @@ FWD = ['tile meta + spans + small vectors', 'in-edge lists', 'row gathers + atte
        'gru epilogue -> LDS (+ barrier)', 'barrier + row stores']
 BWD = ['tile meta + spans + small vectors', 'edge lists + per-edge scalars', 'pull + attention rows', 'barrier',
        'recompute mfma', 'gru backward', 'write dG planes (+2 barriers)', 'dgrad mfma', '(unused)',
-       'd(zbar) tile (+2 barriers)', 'attention backward + row stores', 'dG stores, lds atomics, barrier, slab store']
+       'd(zbar) tile (+2 barriers)', 'row 1 stores (after its attention math)', 'dG stores, lds atomics, barrier, slab store',
+       'row 0: wait for its source rows + attention backward', 'row 1 loads issued + row 0 stores', 'row 1: wait + attention backward']
 
 
 def main():
@@ -44,7 +45,7 @@ def main():
     grads = [torch.zeros_like(t) for t in (attn_u, Wvc, bvc, bih, bhh)]
     ltpl = plan.level_tile_ptr
     widest = max(ltpl[i + 1] - ltpl[i] for i in range(1, len(ltpl) - 1))
-    scratch = torch.empty(plan.n_active * 5 * H + widest * T * 11 * H, device=dev)
+    scratch = torch.empty(plan.n_active * 5 * H + widest * T * 11 * H + 256 * 6 * H * H, device=dev)
     stp = (ctypes.c_int32 * len(plan.slot_tile_ptr))(*plan.slot_tile_ptr)
     stamps = torch.zeros(8 * 16, dtype=torch.int64, device=dev)
     P = lambda t: ctypes.c_void_p(t.data_ptr())
