@@ -292,6 +292,9 @@ int mgv_plan_csr_scratch_ints(int64_t N, int64_t E);                            
 int mgv_plan_csr(int64_t N, int64_t E, const int64_t* src, const int64_t* dst, int32_t* in_ptr, int32_t* in_src, int32_t* in_dst,
                  int32_t* out_ptr, int32_t* out_dst, int32_t* out_slot, int32_t* in_eid /* NULL or [E]: edge id per in-CSR slot */,
                  int32_t* out_eid /* NULL or [E] */, int32_t* scratch, int64_t scratch_ints, int32_t* status, void* stream);
+/* every list vals[ptr[n] .. ptr[n+1]) ascending, in place; scratch: N + 1 + E ints.  Applied to the lists mgv_neg_bucket fills through
+ * atomic cursors: their order then no longer depends on thread arrival (equal values are interchangeable) */
+int mgv_sort_lists_i32(int64_t N, int64_t E, const int32_t* ptr, int32_t* vals, int32_t* scratch, int64_t scratch_ints, void* stream);
 /* ASAP levels by frontier relaxation over the out-CSR; `rounds` level steps are enqueued; done[0] == N afterwards iff complete.
  * scratch: 3 N + rounds + 2 ints */
 int mgv_plan_levels(int64_t N, const int32_t* in_ptr, const int32_t* out_ptr, const int32_t* out_dst, int32_t* level, int rounds,

@@ -12,24 +12,41 @@ namespace mgv {
 constexpr int kSumRows = 2048;
 constexpr int kSumStride = 136;
 
-// 64 outputs per block, 4 row phases per output (rows ty, ty+4, ...), LDS combine in phase order
+// 64 outputs per block, 16 row phases per output (rows ty, ty+16, ...; eight loads in flight per thread), LDS combine in phase
+// order: the result depends on the rows' contents only, never on which workgroup wrote its row first
 template <typename T, typename O>
-static __global__ __launch_bounds__(256) void k_slab_sum(const T* slab, int nwg, int64_t stride, int n, O* out) {
-    __shared__ T red[4][64];
+static __global__ __launch_bounds__(1024) void k_slab_sum(const T* slab, int nwg, int64_t stride, int n, O* out) {
+    constexpr int P = 16;
+    __shared__ T red[P][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + tx;
     T s = 0;
-    if (i < n)
-        for (int g = ty; g < nwg; g += 4) s += slab[(int64_t)g * stride + i];
+    if (i < n) {
+        const T* src = slab + i;
+        int g = ty;
+        for (; g + 7 * P < nwg; g += 8 * P) {
+            T v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = src[(int64_t)(g + k * P) * stride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; g < nwg; g += P) s += src[(int64_t)g * stride];
+    }
     red[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && i < n) out[i] += (O)(((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx]);
+    if (ty == 0 && i < n) {
+        T t = red[0][tx];
+#pragma unroll
+        for (int k = 1; k < P; ++k) t += red[k][tx];
+        out[i] += (O)t;
+    }
 }
 
 template <typename T, typename O>
 static inline void launch_slab_sum(const T* slab, int nwg, int64_t stride, int n, O* out, hipStream_t st) {
     if (n <= 0 || nwg <= 0) return;
-    hipLaunchKernelGGL((k_slab_sum<T, O>), dim3((n + 63) / 64), dim3(256), 0, st, slab, nwg, stride, n, out);
+    hipLaunchKernelGGL((k_slab_sum<T, O>), dim3((n + 63) / 64), dim3(1024), 0, st, slab, nwg, stride, n, out);
 }
 
 }  // namespace mgv

@@ -158,10 +158,10 @@ __global__ __launch_bounds__(1024) void k_sort_heavy(const int32_t* heavy, const
             for (int i = threadIdx.x; i < d; i += 1024) eid[p0 + i] = s_v[i];
             __syncthreads();
         } else {
-            for (int i = threadIdx.x; i < d; i += 1024) {          // edge ids are distinct: rank = number of smaller ids
+            for (int i = threadIdx.x; i < d; i += 1024) {          // rank = number of smaller values (equal ones in index order)
                 const int a = eid[p0 + i];
                 int r = 0;
-                for (int j = 0; j < d; ++j) r += eid[p0 + j] < a;
+                for (int j = 0; j < d; ++j) { const int b = eid[p0 + j]; r += (b < a) || (b == a && j < i); }
                 tmp[p0 + r] = a;
             }
             __syncthreads();
@@ -383,6 +383,22 @@ extern "C" int mgv_plan_csr(int64_t N, int64_t E, const int64_t* src, const int6
     if (out_eid) hipMemcpyAsync(out_eid, eid_out, E * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
     hipLaunchKernelGGL(k_csr_finish_in, dim3(blocks_for(E)), dim3(256), 0, st, E, src, dst, eid_in, in_src, in_dst, pos_in);
     hipLaunchKernelGGL(k_csr_finish_out, dim3(blocks_for(E)), dim3(256), 0, st, E, dst, eid_out, pos_in, out_dst, out_slot);
+    MGV_LAUNCH_RET();
+}
+
+/* every list vals[ptr[n] .. ptr[n+1]) ascending, in place (equal values are interchangeable).  Turns lists filled through atomic
+ * cursors (mgv_neg_bucket) into lists whose order no longer depends on which thread arrived first.  scratch: N + 1 + E ints. */
+extern "C" int mgv_sort_lists_i32(int64_t N, int64_t E, const int32_t* ptr, int32_t* vals, int32_t* scratch, int64_t scratch_ints,
+                                  void* stream) {
+    MGV_CHECK_ARG(N >= 0 && E >= 0 && (N == 0 || (ptr && scratch && scratch_ints >= N + 1 + E)) && (E == 0 || vals));
+    if (N == 0 || E == 0) return MGV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t* heavy = scratch;
+    int32_t* n_heavy = scratch + N;
+    int32_t* tmp = scratch + N + 1;
+    hipMemsetAsync(n_heavy, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL(k_sort_lists, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, ptr, vals, heavy, n_heavy);
+    hipLaunchKernelGGL(k_sort_heavy, dim3(256), dim3(1024), 0, st, heavy, n_heavy, ptr, vals, tmp);
     MGV_LAUNCH_RET();
 }
 

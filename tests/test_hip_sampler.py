@@ -57,6 +57,27 @@ def test_device_sampler_draws_valid_pairs_and_consistent_buckets():
     assert np.mean(np.sort(other[0] * N + other[1]) == np.sort(keys)) < 0.01
 
 
+def test_same_seed_and_call_number_give_identical_buckets():
+    """The buckets are filled through atomic cursors and then sorted per list: the same draw comes out in the same order."""
+    dev = _dev()
+    import itertools
+    from deepgate import sampling
+    batch, plan = _plan(dev, n_graphs=8, nodes=2048)
+    draws = []
+    for _ in range(3):
+        sampling._CALLS = itertools.count()
+        torch.manual_seed(1234)
+        neg = sampling.negative_sampling_device(plan)
+        draws.append([neg.edge_index.clone()] + [t.clone() for t in neg.csr])
+    for other in draws[1:]:
+        for a, b in zip(draws[0], other):
+            assert torch.equal(a, b)
+    ei = draws[0][0].cpu().numpy()
+    out_ptr = draws[0][1].cpu().numpy()
+    for n in np.random.Generator(np.random.PCG64(0)).integers(0, plan.N, size=200):
+        assert np.all(np.diff(ei[1][out_ptr[n]:out_ptr[n + 1]]) >= 0)          # ascending inside a list
+
+
 def test_csr_backward_equals_atomic_backward():
     dev = _dev()
     from deepgate import ops, sampling
