@@ -260,16 +260,17 @@ def main():
 
     def step():
         ls = tr.train_step(batch)
-        # the reference's step ends with a host copy of its metrics (trainer.py:236-244); here: 3 losses + 4 counters
-        return torch.cat([torch.stack([ls['recon_loss'].detach(), ls['prob_loss'].detach(), ls['func_loss'].detach()]).double(),
-                          ls['confusion'].double()]).tolist()
+        # the reference's step ends with a host copy of its metrics (trainer.py:236-244); here: 3 losses + 4 counters, copied
+        # every step into pinned memory and read one step behind (Trainer.enqueue_metrics, as Trainer.train does)
+        return tr.enqueue_metrics(ls)
 
     for _ in range(a.warmup):
         step()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        vals = step()
+        step()
+    vals = tr.flush_metrics()
     sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -312,7 +313,7 @@ def main():
             'dtype': mode, 'data': 'synthetic',
             'nodes_per_s': world * N * a.steps / elapsed,
             'config': {'workload': 'cfg%d: DG_AE --type %s, %d x %d-node synthetic levelised DAGs per GPU (N=%d, E=%d, %d levels), '
-                                   'H=64, 4+4 rounds, layernorm, weights [1,4,4], negatives %s; step includes the 7-scalar metrics copy' % (
+                                   'H=64, 4+4 rounds, layernorm, weights [1,4,4], negatives %s; step includes the 7-scalar metrics copy (pinned, read one step behind)' % (
                                        a.config, ctype, B, cfg['n_nodes'], N, E, cfg['n_levels'], a.neg),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world},
             'plan_ms': plan_ms, 'plan_ms_steady': plan_ms_steady, 'losses': losses, 'roofline': roof,

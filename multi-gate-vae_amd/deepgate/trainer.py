@@ -224,6 +224,42 @@ class Trainer():
         self.optimizer.step()
         return loss_status
 
+    # ---- per-step metrics read-back (trainer.py:236-244: three losses + the confusion counters), one step behind -------------
+    def enqueue_metrics(self, loss_status):
+        """Start the host copy of this step's 7 metrics (3 losses, TP/FP/TN/FN) into pinned memory and return the PREVIOUS
+        step's values (None at the first call): the host never waits for the step it has just enqueued, so the next step's
+        launches are already queued when the GPU finishes this one.  `flush_metrics()` returns the last step's values."""
+        vals = torch.cat([torch.stack([loss_status['recon_loss'].detach(), loss_status['prob_loss'].detach(),
+                                       loss_status['func_loss'].detach()]).double(), loss_status['confusion'].double()])
+        if not vals.is_cuda:
+            prev, self._m_last = getattr(self, '_m_last', None), vals.tolist()
+            return prev
+        if getattr(self, '_m_buf', None) is None:
+            self._m_buf = torch.empty(2, 7, dtype=torch.float64).pin_memory()
+            self._m_ev = [None, None]
+            self._m_n = 0
+        slot = self._m_n % 2
+        prev = self._take_metrics(1 - slot)
+        self._m_buf[slot].copy_(vals, non_blocking=True)
+        self._m_ev[slot] = torch.cuda.Event()
+        self._m_ev[slot].record()
+        self._m_n += 1
+        return prev
+
+    def _take_metrics(self, slot):
+        ev = self._m_ev[slot]
+        if ev is None:
+            return None
+        ev.synchronize()
+        self._m_ev[slot] = None
+        return self._m_buf[slot].tolist()
+
+    def flush_metrics(self):
+        if getattr(self, '_m_buf', None) is None:
+            prev, self._m_last = getattr(self, '_m_last', None), None
+            return prev
+        return self._take_metrics((self._m_n - 1) % 2)
+
     def _loader(self, dataset, shuffle):
         if isinstance(dataset, GraphLoader):
             return dataset
@@ -235,6 +271,16 @@ class Trainer():
         batch_time = AverageMeter()
         stats = {k: AverageMeter() for k in ('recon', 'prob', 'func', 'acc', 'tp', 'fp', 'tn', 'fn')}
         print('[INFO] Start training, lr = {:.4f}'.format(self.optimizer.param_groups[0]['lr']))
+
+        def account(vals):
+            if vals is None:
+                return
+            tot = max(sum(vals[3:]), 1.0)
+            tp, fp, tn, fn = (v / tot for v in vals[3:])
+            for k, v in zip(('recon', 'prob', 'func', 'acc', 'tp', 'fp', 'tn', 'fn'),
+                            (vals[0], vals[1], vals[2], tp + tn, tp, fp, tn, fn)):
+                stats[k].update(v)
+
         for epoch in range(num_epoch):
             for phase in ['train', 'val']:
                 loader = train_loader if phase == 'train' else val_loader
@@ -247,16 +293,11 @@ class Trainer():
                     else:
                         with torch.no_grad():
                             loss_status = self.run_batch(batch, want_pred=False)
-                    # one small device->host copy per step: 3 losses + 4 counters
-                    vals = torch.cat([torch.stack([loss_status['recon_loss'].detach(), loss_status['prob_loss'].detach(),
-                                                   loss_status['func_loss'].detach()]).double(),
-                                      loss_status['confusion'].double()]).tolist()
-                    tot = max(sum(vals[3:]), 1.0)
-                    tp, fp, tn, fn = (v / tot for v in vals[3:])
+                    # one small device->host copy per step (3 losses + 4 counters), read one step behind so that the host
+                    # never waits for the step it has just enqueued
+                    account(self.enqueue_metrics(loss_status))
                     batch_time.update(time.time() - time_stamp)
-                    for k, v in zip(('recon', 'prob', 'func', 'acc', 'tp', 'fp', 'tn', 'fn'),
-                                    (vals[0], vals[1], vals[2], tp + tn, tp, fp, tn, fn)):
-                        stats[k].update(v)
+                account(self.flush_metrics())
                 if phase == 'train' and self.model_epoch % 10 == 0 and self.rank == 0:
                     self.save(os.path.join(self.log_dir, 'model_{:}.pth'.format(self.model_epoch)))
                     self.save(os.path.join(self.log_dir, 'model_last.pth'))
