@@ -319,7 +319,7 @@ def test_vae_sampler_and_kl_vs_reference_fixture():
     assert abs(float(eps.mean())) < 0.05 and abs(float(eps.std()) - 1.0) < 0.05
 
 
-@pytest.mark.parametrize('H,ctype', [(32, 'aig'), (32, 'xmg'), (16, 'mig')])
+@pytest.mark.parametrize('H,ctype', [(32, 'aig'), (32, 'xmg'), (16, 'mig'), (64, 'xag'), (64, 'mig')])
 def test_other_hidden_widths_against_the_oracle(H, ctype):
     """dim_hidden 32 (bf16x3 kernels, split-K wgrad layout) and 16 (exact-fp32 kernels): no reference
     fixture exists at these widths, so the pinned oracle is the checker: same random parameters, same
@@ -330,7 +330,7 @@ def test_other_hidden_widths_against_the_oracle(H, ctype):
     from oracle import ref_cpu as R
     torch.manual_seed(5)
     enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=H, s_rounds=2, t_rounds=2, layernorm=True)
-    mod = {'aig': deepgate.dg_ae_model_aig, 'mig': deepgate.dg_ae_model_mig, 'xmg': deepgate.dg_ae_model_xmg}[ctype]
+    mod = getattr(deepgate, 'dg_ae_model_' + ctype)
     model = mod.Model(struct_encoder=enc, dim_hidden=H)
     with torch.no_grad():
         for m in model.modules():
