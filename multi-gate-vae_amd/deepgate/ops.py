@@ -117,7 +117,7 @@ _WS = {}
 def workspace(nfloats, device, dtype=F32):
     """Scratch for the deterministic cross-workgroup sums (per-workgroup partial rows, csrc/mgv_slab.h): one growing buffer
     per (device, stream, dtype); launches on a stream are ordered, so consecutive users may share it."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == 'cuda' else 0, dtype)
+    key = (str(device), _hip.stream().value if torch.device(device).type == 'cuda' else 0, dtype)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nfloats:
         buf = _WS[key] = torch.empty(max(int(nfloats), 1), dtype=dtype, device=device)
