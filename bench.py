@@ -316,7 +316,10 @@ def main():
                                    'H=64, 4+4 rounds, layernorm, weights [1,4,4], negatives %s; step includes the 7-scalar metrics copy (pinned, read one step behind)' % (
                                        a.config, ctype, B, cfg['n_nodes'], N, E, cfg['n_levels'], a.neg),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world},
-            'plan_ms': plan_ms, 'plan_ms_steady': plan_ms_steady, 'losses': losses, 'roofline': roof,
+            'plan_ms': plan_ms, 'plan_ms_steady': plan_ms_steady,
+            # the rate a loop over FRESH batches would see: every step also builds its batch plan (CSRs, level tiles) on the device
+            'value_with_plan_build': world * B / (elapsed / a.steps + plan_ms_steady * 1e-3),
+            'losses': losses, 'roofline': roof,
         }
         if allreduce_ms is not None:
             out['allreduce_ms'] = allreduce_ms
