@@ -563,7 +563,8 @@ extern "C" int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, con
                                         const float* bhh, const float* ln_w, const float* ln_b, float ln_eps,
                                         const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
                                         float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
-                                        float* dln_b, float* workspace, int64_t workspace_floats, void* stream) {
+                                        float* dln_b, float* workspace, int64_t workspace_floats, int heavy_n,
+                                        const int32_t* heavy_nodes, float* heavy_ws, void* stream) {
     MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && gy_direct);
     MGV_CHECK_ARG(dWc && dbc && dWhh && dbhh && dxtab);
     MGV_CHECK_ARG(C >= 1 && C <= mgv::kMaxClsX3);
@@ -581,5 +582,7 @@ extern "C" int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, con
     MGV_SET_STAMPS2(a);
     { static const int v = [] { const char* e = getenv("MGV_XCD_TILES"); return (e && e[0] == '0') ? 0 : 1; }(); a.xcd = v; }
     { static const int v = [] { const char* e = getenv("MGV_ROW_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }(); a.prefetch = v; }
+    MGV_CHECK_ARG(heavy_n >= 0 && (heavy_n == 0 || (heavy_nodes && heavy_ws)));
+    mgv::launch_heavy_sums<64>(a, heavy_n, heavy_nodes, heavy_ws, gy_agg != nullptr, static_cast<hipStream_t>(stream));
     return mgv::launch_bwd2_x3(a, workspace, workspace_floats, static_cast<hipStream_t>(stream));
 }

@@ -656,8 +656,9 @@ static int xcd_tiles() {
 extern "C" int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
                                        const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
                                        const float* bhh, const float* ln_w, const float* ln_b, float ln_eps, float* h_out,
-                                       void* stream) {
+                                       int heavy_n, const int32_t* heavy_nodes, float* heavy_ws, void* stream) {
     MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && h_out);
+    MGV_CHECK_ARG(heavy_n >= 0 && (heavy_n == 0 || (heavy_nodes && heavy_ws)));
     MGV_CHECK_ARG(C >= 1 && C <= mgv::kMaxClsX3);
     MGV_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr));
     if (N == 0) return MGV_OK;
@@ -669,8 +670,8 @@ extern "C" int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, cons
     a.xcd = xcd_tiles();
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (H) {
-        case 32: return mgv::launch_fwd_x3<32>(a, st);
-        case 64: return mgv::launch_fwd_x3<64>(a, st);
+        case 32: mgv::launch_heavy_sums<32>(a, heavy_n, heavy_nodes, heavy_ws, false, st); return mgv::launch_fwd_x3<32>(a, st);
+        case 64: mgv::launch_heavy_sums<64>(a, heavy_n, heavy_nodes, heavy_ws, false, st); return mgv::launch_fwd_x3<64>(a, st);
         default: return MGV_EUNSUPPORTED;
     }
 }
@@ -680,8 +681,9 @@ extern "C" int mgv_struct_stage_bwd_x3(int H, int64_t N, const float* h_in, cons
                                        const float* bhh, const float* ln_w, const float* ln_b, float ln_eps,
                                        const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
                                        float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
-                                       float* dln_b, void* stream) {
+                                       float* dln_b, int heavy_n, const int32_t* heavy_nodes, float* heavy_ws, void* stream) {
     MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && gy_direct);
+    MGV_CHECK_ARG(heavy_n >= 0 && (heavy_n == 0 || (heavy_nodes && heavy_ws)));
     MGV_CHECK_ARG(dWc && dbc && dWhh && dbhh && dxtab);
     MGV_CHECK_ARG(C >= 1 && C <= mgv::kMaxClsX3);
     MGV_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr));
@@ -698,8 +700,8 @@ extern "C" int mgv_struct_stage_bwd_x3(int H, int64_t N, const float* h_in, cons
     a.xcd = xcd_tiles();
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (H) {
-        case 32: return mgv::launch_bwd_x3<32>(a, st);
-        case 64: return mgv::launch_bwd_x3<64>(a, st);
+        case 32: mgv::launch_heavy_sums<32>(a, heavy_n, heavy_nodes, heavy_ws, gy_agg != nullptr, st); return mgv::launch_bwd_x3<32>(a, st);
+        case 64: mgv::launch_heavy_sums<64>(a, heavy_n, heavy_nodes, heavy_ws, gy_agg != nullptr, st); return mgv::launch_bwd_x3<64>(a, st);
         default: return MGV_EUNSUPPORTED;
     }
 }

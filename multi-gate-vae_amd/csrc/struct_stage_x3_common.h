@@ -30,6 +30,9 @@ struct StageX3Args {
     float* g_direct_out;
     float* g_agg_out;
     float* dWc; float* dbc; float* dWhh; float* dbhh; float* dxtab; float* dlnw; float* dlnb;
+    // rows with more than kHeavyRow neighbours (a clock/reset-like net), ascending node ids, and their neighbour sums formed by
+    // k_heavy_sums before the stage kernel starts: [heavy_n][H] over h_in, then [heavy_n][H] over gy_agg (backward only)
+    int heavy_n; const int32_t* heavy_nodes; const float* heavy_a; const float* heavy_g;
 };
 
 #include "mgv_stamps.h"
@@ -271,7 +274,11 @@ __device__ __forceinline__ void rows_chunked(const StageX3Args& a, int64_t base,
     }
 }
 
-// generic degree: per-row loops (rare tiles with a high fan-out node or an index list beyond LDS)
+// generic degree: per-row loops (rare tiles with a high fan-out node or an index list beyond LDS).  A row with more than kHeavyRow
+// neighbours takes its sums from the pre-pass (k_heavy_sums) when the caller listed it: walked here, one neighbour after the other
+// by a single lane group, a 100,000-consumer net costs 38 ms per launch.
+constexpr int kHeavyRow = 64;
+
 template <int H, bool DY>
 __device__ __forceinline__ void row_generic(const StageX3Args& a, int64_t node, int row, int lr, const int* s_ptr, bool two,
                                             float4& acc, float4& own, float4& dy, float& deg, int& cls) {
@@ -282,11 +289,84 @@ __device__ __forceinline__ void row_generic(const StageX3Args& a, int64_t node, 
     own = ld4(a.h_in + node * H + 4 * lr);
     if (DY) dy = ld4(a.gy_direct + node * H + 4 * lr);
     cls = a.xcls[node];
+    if (p1 - p0 > kHeavyRow && a.heavy_n > 0) {
+        int lo = 0, hi = a.heavy_n - 1, k = -1;
+        while (lo <= hi) {
+            const int mid = (lo + hi) >> 1, v = a.heavy_nodes[mid];
+            if (v == (int)node) { k = mid; break; }
+            if (v < (int)node) lo = mid + 1; else hi = mid - 1;
+        }
+        if (k >= 0) {
+            acc = ld4(a.heavy_a + (int64_t)k * H + 4 * lr);
+            if (DY && two) dy = add4(dy, ld4(a.heavy_g + (int64_t)k * H + 4 * lr));
+            return;
+        }
+    }
     for (int e = p0; e < p1; ++e) {
         const int64_t jj = a.idx[e];
         acc = add4(acc, ld4(a.h_in + jj * H + 4 * lr));
         if (DY && two) dy = add4(dy, ld4(a.gy_agg + jj * H + 4 * lr));
     }
+}
+
+// Neighbour sums of the listed heavy rows, one 256-thread workgroup per row: lane group g takes neighbours g, g + 16, ... (four in
+// flight), the 16 partial sums meet in LDS and are added in group order (deterministic).  out_a[k] = sum h_in[nbr], out_g[k] = sum
+// gy_agg[nbr] (gy_agg nullable).
+template <int H>
+static __global__ __launch_bounds__(256) void k_heavy_sums(int K, const int32_t* nodes, const int32_t* ptr, const int32_t* idx,
+                                                           const float* src_a, const float* src_g, float* out_a, float* out_g) {
+    constexpr int LPR = H / 4, G = 256 / LPR;
+    __shared__ __attribute__((aligned(16))) float s_p[2][G][H];
+    const int lr = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    for (int k = blockIdx.x; k < K; k += gridDim.x) {
+        const int node = nodes[k];
+        const int p0 = ptr[node], p1 = ptr[node + 1];
+        float4 sa = zero4(), sg = zero4();
+        int e = p0 + grp;
+        for (; e + 3 * G < p1; e += 4 * G) {
+            int64_t j[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) j[u] = idx[e + u * G];
+            float4 va[4], vg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                va[u] = ld4(src_a + j[u] * H + 4 * lr);
+                if (src_g) vg[u] = ld4(src_g + j[u] * H + 4 * lr);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sa = add4(sa, va[u]);
+                if (src_g) sg = add4(sg, vg[u]);
+            }
+        }
+        for (; e < p1; e += G) {
+            const int64_t jj = idx[e];
+            sa = add4(sa, ld4(src_a + jj * H + 4 * lr));
+            if (src_g) sg = add4(sg, ld4(src_g + jj * H + 4 * lr));
+        }
+        __syncthreads();
+        st4(&s_p[0][grp][4 * lr], sa);
+        st4(&s_p[1][grp][4 * lr], sg);
+        __syncthreads();
+        if (grp == 0) {
+            float4 ta = zero4(), tg = zero4();
+            for (int g = 0; g < G; ++g) { ta = add4(ta, ld4(&s_p[0][g][4 * lr])); tg = add4(tg, ld4(&s_p[1][g][4 * lr])); }
+            st4(out_a + (int64_t)k * H + 4 * lr, ta);
+            if (src_g) st4(out_g + (int64_t)k * H + 4 * lr, tg);
+        }
+    }
+}
+
+// pre-pass of a stage launch: fills a.heavy_a / a.heavy_g from `ws` ([2][heavy_n][H] floats); no-op without heavy rows
+template <int H>
+static inline void launch_heavy_sums(StageX3Args& a, int heavy_n, const int32_t* heavy_nodes, float* ws, bool with_g, hipStream_t st) {
+    a.heavy_n = 0;
+    if (heavy_n <= 0 || heavy_nodes == nullptr || ws == nullptr) return;
+    float* out_a = ws;
+    float* out_g = ws + (int64_t)heavy_n * H;
+    const float* src_g = with_g ? a.gy_agg : nullptr;
+    hipLaunchKernelGGL(k_heavy_sums<H>, dim3(heavy_n < 1024 ? heavy_n : 1024), dim3(256), 0, st, heavy_n, heavy_nodes, a.ptr, a.idx, a.h_in, src_g, out_a, out_g);
+    a.heavy_n = heavy_n; a.heavy_nodes = heavy_nodes; a.heavy_a = out_a; a.heavy_g = out_g;
 }
 
 template <int H, int RPG, bool DY, int D = 2>

@@ -116,6 +116,19 @@ class GraphPlan:
         edges are flipped (`r_edge_index`, digae_layer.py:264)."""
         return (self.out_ptr, self.out_dst) if reverse else (self.in_ptr, self.in_src)
 
+    HEAVY_ROW = 64      # csrc/struct_stage_x3_common.h: kHeavyRow
+
+    def heavy(self, reverse):
+        """(count, node ids int32 ascending) of the nodes with more than HEAVY_ROW neighbours in `csr(reverse)` — clock/reset-like
+        nets.  The struct-stage launchers sum such lists in a pre-pass (one workgroup per node).  Built once per plan and direction
+        (one host round trip); empty on most batches."""
+        cache = self.__dict__.setdefault('_heavy', {})
+        if reverse not in cache:
+            p = self.csr(reverse)[0]
+            nodes = torch.nonzero((p[1:] - p[:-1]) > self.HEAVY_ROW).reshape(-1).to(torch.int32)
+            cache[reverse] = (int(nodes.numel()), nodes.contiguous())
+        return cache[reverse]
+
     def first_stage_classes(self, xcls, max_classes=256):
         """(degree, feature class) pairs of the forward CSR: every node enters the first half round of an encoder with
         the same state (ones, digae_layer.py:260), so its output row there depends on that pair alone.  Returns

@@ -86,7 +86,18 @@ def _zeros_like_params(*ts):
 # ------------------------------------------------------------------------------------------------
 # structural encoder half round (digae_layer.py:267-275)
 # ------------------------------------------------------------------------------------------------
-def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, out=None, wpack=None):
+def _heavy_args(heavy, H, device):
+    """(heavy_n, heavy_nodes, heavy_ws) of a stage launch; `heavy` = GraphPlan.heavy(reverse) or None."""
+    if heavy is None or heavy[0] == 0:
+        return 0, None, None
+    n, nodes = heavy
+    hw = _WS.get(('heavy', str(device)))
+    if hw is None or hw.numel() < 2 * n * H:
+        hw = _WS[('heavy', str(device))] = torch.empty(2 * n * H, dtype=F32, device=device)
+    return n, ptr(nodes), ptr(hw)
+
+
+def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, out=None, wpack=None, heavy=None):
     N, H = h_in.shape
     check(h_in, F32, 'h_in'); check(nbr_ptr, I32, 'nbr_ptr'); check(nbr_idx, I32, 'nbr_idx'); check(xcls, U8, 'xcls')
     for n, t in (('xtab', xtab), ('Wc', Wc), ('bc', bc), ('Whh', Whh), ('bhh', bhh)):
@@ -98,7 +109,7 @@ def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
     if use_x3(H):
         wpack = stage_wpack(Wc, Whh) if wpack is None else wpack
         _hip.call('mgv_struct_stage_fwd_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
-                  xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(h_out))
+                  xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(h_out), *_heavy_args(heavy, H, h_in.device))
         return h_out
     _hip.call('mgv_struct_stage_fwd', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
               xtab.shape[0], ptr(Wc), ptr(bc), ptr(Whh), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(h_out))
@@ -140,7 +151,7 @@ def _stage_ws(H, N, device):
 
 
 def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, gy_direct, gy_agg,
-                     grads, need_input_grad=True, wpack=None):
+                     grads, need_input_grad=True, wpack=None, heavy=None):
     """`grads` = dict of fp32 accumulators (dWc, dbc, dWhh, dbhh, dxtab, dln_w, dln_b), added to."""
     N, H = h_in.shape
     check(gy_direct, F32, 'gy_direct'); check(gy_agg, F32, 'gy_agg')
@@ -153,7 +164,7 @@ def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
                   xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(gy_direct),
                   ptr(gy_agg), ptr(g_direct), ptr(g_agg), ptr(grads['dWc']), ptr(grads['dbc']), ptr(grads['dWhh']),
                   ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')),
-                  ptr(ws), ws.numel())
+                  ptr(ws), ws.numel(), *_heavy_args(heavy, H, h_in.device))
         return g_direct, g_agg
     if use_x3(H):
         g_direct = torch.empty_like(h_in) if need_input_grad else None
@@ -162,7 +173,7 @@ def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
         _hip.call('mgv_struct_stage_bwd_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
                   xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(gy_direct),
                   ptr(gy_agg), ptr(g_direct), ptr(g_agg), ptr(grads['dWc']), ptr(grads['dbc']), ptr(grads['dWhh']),
-                  ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')))
+                  ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')), *_heavy_args(heavy, H, h_in.device))
         return g_direct, g_agg
     WcT = Wc.t().contiguous()
     WhhT = Whh.t().contiguous()
@@ -211,7 +222,7 @@ class StructEncoderFn(torch.autograd.Function):
                     h = torch.empty(N, H, dtype=F32, device=dev)
                     _hip.call('mgv_class_expand', H, N, ptr(table), ptr(cid), ptr(h))
                 else:
-                    h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)])
+                    h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)], heavy=plan.heavy(rev))
         ctx.plan, ctx.xcls, ctx.rounds, ctx.packs, ctx.first = plan, xcls, rounds, packs, first
         ctx.par, ctx.lw, ctx.lb, ctx.states = par, lw, lb, states
         return h
@@ -246,7 +257,8 @@ class StructEncoderFn(torch.autograd.Function):
                                      lw, lb, gsum, None, g, need_input_grad=False, wpack=ctx.packs[0])
                 else:
                     g_direct, g_agg = struct_stage_bwd(ctx.states[k], p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb,
-                                                       g_direct, g_agg, g, need_input_grad=(k > 0), wpack=ctx.packs[int(rev)])
+                                                       g_direct, g_agg, g, need_input_grad=(k > 0), wpack=ctx.packs[int(rev)],
+                                                       heavy=plan.heavy(rev))
                 k -= 1
         ctx.states = None
         f, r = acc['f'], acc['r']
