@@ -184,7 +184,15 @@ int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t
                           const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
                           const float* bhh, const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc,
                           float* d_attn_u, float* dWvc, float* dbvc, float* dbih, float* dbhh, float* scratch,
-                          int64_t scratch_elems, void* stream);
+                          int64_t scratch_elems,
+                          int skip_inactive_longer_than /* > 0: never-updated nodes with more consumers are left to mgv_sweep_pull_heavy */,
+                          void* stream);
+/* ghs rows of the heavy never-updated nodes (primary inputs driving thousands of gates): consumer lists in segments, one workgroup
+ * each (GraphPlan.heavy_segments(reverse=True, inactive_only=True)); partial_ws: S * H floats */
+int mgv_sweep_pull_heavy(int H, int K, const int32_t* nodes, const int32_t* node_seg_ptr, int S, const int32_t* seg_e0,
+                         const int32_t* seg_e1, const int32_t* out_dst, const int32_t* out_slot, const uint8_t* gslot,
+                         const float* alpha, const float* dsc, const float* dzb, const float* attn_u, float* partial_ws,
+                         float* ghs, void* stream);
 
 /* ---- inner-product decoder and reconstruction loss (digae_layer.py:26-29, dg_ae_model_aig.py:108-130).
  * s, t: row pointers with common row stride ld (the two halves of hs_decompose's output);
@@ -212,7 +220,14 @@ int mgv_recon_loss_bwd(int H, int64_t N, const float* s, const float* t, int ld,
 int mgv_recon_loss_bwd_csr(int H, int64_t N, const float* s, const float* t, int ld, const int32_t* pos_out_ptr,
                            const int32_t* pos_out_dst, const int32_t* pos_in_ptr, const int32_t* pos_in_src, int64_t Epos,
                            const int32_t* neg_out_ptr, const int32_t* neg_out_dst, const int32_t* neg_in_ptr,
-                           const int32_t* neg_in_src, int64_t Eneg, const float* gscale, float* ds, float* dt, void* stream);
+                           const int32_t* neg_in_src, int64_t Eneg, const float* gscale, float* ds, float* dt,
+                           int skip_pos_longer_than /* > 0: positive lists longer than this are left to mgv_recon_heavy_lists */, void* stream);
+/* the positive lists mgv_recon_loss_bwd_csr skipped (nodes with thousands of consumers / producers): cut into segments
+ * (nodes[K], node_seg_ptr[K+1], seg_node/seg_e0/seg_e1[S]: GraphPlan.heavy_segments), one workgroup per segment, partials
+ * [S][H] in partial_ws, added into out (= ds for which 0 with list = pos_out_dst, = dt for which 1 with list = pos_in_src) */
+int mgv_recon_heavy_lists(int H, const float* s, const float* t, int ld, int64_t Epos, const float* gscale, int K,
+                          const int32_t* nodes, const int32_t* node_seg_ptr, int S, const int32_t* seg_node, const int32_t* seg_e0,
+                          const int32_t* seg_e1, const int32_t* list, int which, float* partial_ws, float* out, void* stream);
 /* negative sampling of the reconstruction loss (dg_ae_model_aig.py:115-119, torch_geometric negative_sampling): E pairs
  * uniform over {(u, v): u != v, (u, v) not an edge of the CSR}, from a counter-based generator (seed); cnt_out/cnt_in
  * [N] (zeroed by the caller) receive the pairs' per-source / per-destination counts.  mgv_neg_bucket then buckets the

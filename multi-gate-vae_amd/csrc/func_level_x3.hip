@@ -46,6 +46,7 @@ struct LevelX3Args {
     float* dgrows;         // [n_active][3H] gate gradients and
     float* zrows;          // [n_active][2H] zbar rows in sweep order, for the weight-gradient kernel
     const int32_t* slot_tiles;   // tiles grouped by slot
+    int skip_inactive;           // > 0: the inactive-node pull skips nodes with more consumers (mgv_sweep_pull_heavy writes their rows)
 };
 
 // kLW waves over a (64 rows) x COLS output: across column tiles first, then row tiles
@@ -679,9 +680,58 @@ __global__ __launch_bounds__(kThreads) void k_level_pull_inactive_x3(LevelX3Args
     const int64_t stride = (int64_t)gridDim.x * (kThreads / LPR);
     for (int64_t node = (int64_t)blockIdx.x * (kThreads / LPR) + threadIdx.x / LPR; node < a.N; node += stride) {
         if (a.gslot[node] != kNoGateX) continue;
+        if (a.skip_inactive > 0 && a.out_ptr[node + 1] - a.out_ptr[node] > a.skip_inactive) continue;      // left to mgv_sweep_pull_heavy
         float4 gs = zero4(), gf = zero4();
-        pull_tail<H>(a, a.out_ptr[node], a.out_ptr[node + 1], lr, gs, gf);
+        // four consumers in flight: a primary input is where the long consumer lists are (a clock- or reset-like net)
+        const int e1 = a.out_ptr[node + 1];
+        int e = a.out_ptr[node];
+        for (; e + 4 <= e1; e += 4) {
+            int64_t c[4]; int gc[4], sl[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { c[k] = a.out_dst[e + k]; sl[k] = a.out_slot[e + k]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gc[k] = a.gslot[c[k]];
+            float al[4], ds[4]; float4 dz[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                al[k] = 0.f; ds[k] = 0.f; dz[k] = zero4();
+                if (gc[k] != kNoGateX) { al[k] = a.alpha[sl[k]]; ds[k] = a.dsc[sl[k]]; dz[k] = ld4(a.dzb + c[k] * 2 * H + 4 * lr); }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (gc[k] != kNoGateX) gs = fma4(al[k], dz[k], fma4(ds[k], ld4(a.attn_u + (int64_t)gc[k] * 2 * H + 4 * lr), gs));
+        }
+        pull_tail<H>(a, e, e1, lr, gs, gf);
         st4(a.ghs + node * H + 4 * lr, gs);
+    }
+}
+
+// One segment of a heavy never-updated node's consumer list per workgroup (a primary input that drives thousands of gates): the
+// hs-half of the pull, sum over consumers c of alpha_e dzb[c][:H] + dsc_e u_g(c)[:H]; 16 lane groups strided, LDS sum in group order.
+template <int H>
+__global__ __launch_bounds__(256) void k_pull_heavy_seg(int S, const int32_t* seg_e0, const int32_t* seg_e1, const int32_t* out_dst,
+                                                        const int32_t* out_slot, const uint8_t* gslot, const float* alpha, const float* dsc,
+                                                        const float* dzb, const float* attn_u, float* partial) {
+    constexpr int LPR = H / 4, G = 256 / LPR;
+    __shared__ __attribute__((aligned(16))) float s_p[G][H];
+    const int lr = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    for (int sg = blockIdx.x; sg < S; sg += gridDim.x) {
+        float4 gs = zero4();
+        for (int e = seg_e0[sg] + grp; e < seg_e1[sg]; e += G) {
+            const int64_t c = out_dst[e];
+            const int gc = gslot[c];
+            if (gc == kNoGateX) continue;
+            const int sl = out_slot[e];
+            gs = fma4(alpha[sl], ld4(dzb + c * 2 * H + 4 * lr), fma4(dsc[sl], ld4(attn_u + (int64_t)gc * 2 * H + 4 * lr), gs));
+        }
+        __syncthreads();
+        st4(&s_p[grp][4 * lr], gs);
+        __syncthreads();
+        if (grp == 0) {
+            float4 tot = zero4();
+            for (int g = 0; g < G; ++g) tot = add4(tot, ld4(&s_p[g][4 * lr]));
+            st4(partial + (int64_t)sg * H + 4 * lr, tot);
+        }
     }
 }
 
@@ -893,7 +943,7 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
                                      const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
                                      const float* bhh, const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc,
                                      float* d_attn_u, float* dWvc, float* dbvc, float* dbih, float* dbhh, float* scratch,
-                                     int64_t scratch_elems, void* stream) {
+                                     int64_t scratch_elems, int skip_inactive_longer_than, void* stream) {
     MGV_CHECK_ARG(N >= 0 && T >= 1 && T <= mgv::kMaxSlots && num_levels >= 0 && n_active >= 0 && level_tile_ptr_host && hs && hf &&
                   attn_u && wpack_bf16 && bvc && bih && bhh);
     MGV_CHECK_ARG(in_ptr && out_ptr && gslot && ghf && ghs && dzb && d_attn_u && dWvc && dbvc && dbih && dbhh);
@@ -905,7 +955,7 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
     a.wpack = static_cast<const __bf16*>(wpack_bf16); a.bvc = bvc; a.bih = bih; a.bhh = bhh;
     a.out_ptr = out_ptr; a.out_dst = out_dst; a.out_slot = out_slot; a.gslot = gslot;
     a.ghf = ghf; a.ghs = ghs; a.dzb = dzb; a.alpha = alpha; a.dsc = dsc; a.d_attn_u = d_attn_u; a.dWvc = dWvc; a.dbvc = dbvc;
-    a.dbih = dbih; a.dbhh = dbhh;
+    a.dbih = dbih; a.dbhh = dbhh; a.skip_inactive = skip_inactive_longer_than;
     hipStream_t st = static_cast<hipStream_t>(stream);
     int nslab = 0;
     for (int lv = 1; lv < num_levels; ++lv) nslab = std::max(nslab, level_tile_ptr_host[lv + 1] - level_tile_ptr_host[lv]);
@@ -952,5 +1002,25 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
         case 64: hipLaunchKernelGGL(mgv::k_level_pull_inactive_x3<64>, dim3(grid), dim3(mgv::kThreads), 0, st, a); break;
         default: return MGV_EUNSUPPORTED;
     }
+    MGV_LAUNCH_RET();
+}
+
+// ghs[nodes[k]] = the pull of heavy never-updated nodes (skipped by mgv_func_sweep_bwd_x3 when skip_inactive_longer_than > 0), their
+// consumer lists cut into segments (GraphPlan.heavy_segments), one workgroup per segment, partials added in segment order
+extern "C" int mgv_sweep_pull_heavy(int H, int K, const int32_t* nodes, const int32_t* node_seg_ptr, int S, const int32_t* seg_e0,
+                                    const int32_t* seg_e1, const int32_t* out_dst, const int32_t* out_slot, const uint8_t* gslot,
+                                    const float* alpha, const float* dsc, const float* dzb, const float* attn_u, float* partial_ws,
+                                    float* ghs, void* stream) {
+    MGV_CHECK_ARG(K >= 0 && S >= 0 && ghs);
+    if (K == 0 || S == 0) return MGV_OK;
+    MGV_CHECK_ARG(nodes && node_seg_ptr && seg_e0 && seg_e1 && out_dst && out_slot && gslot && alpha && dsc && dzb && attn_u && partial_ws);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = S < 4096 ? S : 4096;
+    switch (H) {
+        case 32: hipLaunchKernelGGL(mgv::k_pull_heavy_seg<32>, dim3(grid), dim3(256), 0, st, S, seg_e0, seg_e1, out_dst, out_slot, gslot, alpha, dsc, dzb, attn_u, partial_ws); break;
+        case 64: hipLaunchKernelGGL(mgv::k_pull_heavy_seg<64>, dim3(grid), dim3(256), 0, st, S, seg_e0, seg_e1, out_dst, out_slot, gslot, alpha, dsc, dzb, attn_u, partial_ws); break;
+        default: return MGV_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(mgv::k_heavy_add, dim3((K + 15) / 16 < 1024 ? (K + 15) / 16 : 1024), dim3(256), 0, st, K, H, nodes, node_seg_ptr, partial_ws, ghs, H, 0);
     MGV_LAUNCH_RET();
 }

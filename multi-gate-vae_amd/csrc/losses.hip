@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kThreads) void k_recon_bwd_pull2(int64_t N, const f
                                                               const int32_t* pout_ptr, const int32_t* pout_dst, const int32_t* pin_ptr,
                                                               const int32_t* pin_src, int64_t Ep, const int32_t* nout_ptr,
                                                               const int32_t* nout_dst, const int32_t* nin_ptr, const int32_t* nin_src,
-                                                              int64_t En, const float* gscale, float* ds, float* dt) {
+                                                              int64_t En, const float* gscale, float* ds, float* dt, int skip_len) {
     constexpr int LPR = H / 4, RPB = kThreads / LPR;
     const int lr = threadIdx.x % LPR, slot = threadIdx.x / LPR;
     const float wp = Ep > 0 ? -(*gscale) / (float)Ep : 0.f, wn = En > 0 ? (*gscale) / (float)En : 0.f;
@@ -167,12 +167,27 @@ __global__ __launch_bounds__(kThreads) void k_recon_bwd_pull2(int64_t N, const f
         const float4 su = ld4(s + u * ld + 4 * lr), tu = ld4(t + u * ld + 4 * lr);
         float4 gs = zero4(), gt = zero4();
         if (Ep > 0) {
-            for (int e = pout_ptr[u]; e < pout_ptr[u + 1]; ++e) {
-                const float4 tv = ld4(t + (int64_t)pout_dst[e] * ld + 4 * lr);
-                const float p = sigmoidf_(group_sum<LPR>(dot4(su, tv)));
-                gs = fma4(wp * p * (1.0f - p) / (p + 1e-15f), tv, gs);
+            {   // four partner rows in flight: the positive out-lists are where the long lists are (high fan-out nets)
+                int e1 = pout_ptr[u + 1];
+                int e = pout_ptr[u];
+                if (skip_len > 0 && e1 - e > skip_len) e1 = e;       // a heavy list: left to mgv_recon_heavy_lists (one workgroup per segment)
+                for (; e + 4 <= e1; e += 4) {
+                    float4 tv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) tv[k] = ld4(t + (int64_t)pout_dst[e + k] * ld + 4 * lr);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float p = sigmoidf_(group_sum<LPR>(dot4(su, tv[k])));
+                        gs = fma4(wp * p * (1.0f - p) / (p + 1e-15f), tv[k], gs);
+                    }
+                }
+                for (; e < e1; ++e) {
+                    const float4 tv = ld4(t + (int64_t)pout_dst[e] * ld + 4 * lr);
+                    const float p = sigmoidf_(group_sum<LPR>(dot4(su, tv)));
+                    gs = fma4(wp * p * (1.0f - p) / (p + 1e-15f), tv, gs);
+                }
             }
-            for (int e = pin_ptr[u]; e < pin_ptr[u + 1]; ++e) {
+            for (int e = pin_ptr[u], ee = (skip_len > 0 && pin_ptr[u + 1] - pin_ptr[u] > skip_len) ? pin_ptr[u] : pin_ptr[u + 1]; e < ee; ++e) {
                 const float4 sv = ld4(s + (int64_t)pin_src[e] * ld + 4 * lr);
                 const float p = sigmoidf_(group_sum<LPR>(dot4(sv, tu)));
                 gt = fma4(wp * p * (1.0f - p) / (p + 1e-15f), sv, gt);
@@ -192,6 +207,38 @@ __global__ __launch_bounds__(kThreads) void k_recon_bwd_pull2(int64_t N, const f
         }
         st4(ds + u * ld + 4 * lr, gs);
         st4(dt + u * ld + 4 * lr, gt);
+    }
+}
+
+// One segment of a heavy positive list per workgroup: sum over the segment's partners p of c(own, p) * row(p), c from the own row's
+// dot product with the partner (which = 0: own s[u], partners t[.], result for ds[u]; which = 1: own t[u], partners s[.], for dt[u]).
+// The 16 lane groups take partners strided, their partial sums meet in LDS in group order: deterministic.
+template <int H>
+__global__ __launch_bounds__(256) void k_recon_heavy_seg(int S, const int32_t* seg_node, const int32_t* seg_e0, const int32_t* seg_e1,
+                                                         const int32_t* nodes, const float* s, const float* t, int ld, const int32_t* list,
+                                                         int which, int64_t Ep, const float* gscale, float* partial) {
+    constexpr int LPR = H / 4, G = 256 / LPR;
+    __shared__ __attribute__((aligned(16))) float s_p[G][H];
+    const int lr = threadIdx.x % LPR, grp = threadIdx.x / LPR;
+    const float wp = -(*gscale) / (float)Ep;
+    for (int sg = blockIdx.x; sg < S; sg += gridDim.x) {
+        const int64_t u = nodes[seg_node[sg]];
+        const float4 own = ld4((which ? t : s) + u * ld + 4 * lr);
+        const float* other = which ? s : t;
+        float4 acc = zero4();
+        for (int e = seg_e0[sg] + grp; e < seg_e1[sg]; e += G) {
+            const float4 v = ld4(other + (int64_t)list[e] * ld + 4 * lr);
+            const float p = sigmoidf_(group_sum<LPR>(dot4(own, v)));
+            acc = fma4(wp * p * (1.0f - p) / (p + 1e-15f), v, acc);
+        }
+        __syncthreads();
+        st4(&s_p[grp][4 * lr], acc);
+        __syncthreads();
+        if (grp == 0) {
+            float4 tot = zero4();
+            for (int g = 0; g < G; ++g) tot = add4(tot, ld4(&s_p[g][4 * lr]));
+            st4(partial + (int64_t)sg * H + 4 * lr, tot);
+        }
     }
 }
 
@@ -500,15 +547,29 @@ extern "C" int mgv_recon_loss_bwd(int H, int64_t N, const float* s, const float*
 extern "C" int mgv_recon_loss_bwd_csr(int H, int64_t N, const float* s, const float* t, int ld, const int32_t* pos_out_ptr,
                                       const int32_t* pos_out_dst, const int32_t* pos_in_ptr, const int32_t* pos_in_src, int64_t Epos,
                                       const int32_t* neg_out_ptr, const int32_t* neg_out_dst, const int32_t* neg_in_ptr,
-                                      const int32_t* neg_in_src, int64_t Eneg, const float* gscale, float* ds, float* dt, void* stream) {
-    MGV_CHECK_ARG(s && t && gscale && ds && dt && Epos >= 0 && Eneg >= 0 && N >= 0 && ld >= H && ld % 4 == 0);
+                                      const int32_t* neg_in_src, int64_t Eneg, const float* gscale, float* ds, float* dt,
+                                      int skip_pos_longer_than, void* stream) {
+    MGV_CHECK_ARG(s && t && gscale && ds && dt && Epos >= 0 && Eneg >= 0 && N >= 0 && ld >= H && ld % 4 == 0 && skip_pos_longer_than >= 0);
     MGV_CHECK_ARG(Epos == 0 || (pos_out_ptr && pos_out_dst && pos_in_ptr && pos_in_src));
     MGV_CHECK_ARG(Eneg == 0 || (neg_out_ptr && neg_out_dst && neg_in_ptr && neg_in_src));
     if (N == 0) return MGV_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_recon_bwd_pull2<HH>), dim3(mgv::items_grid(N, mgv::kThreads / (HH / 4))), dim3(mgv::kThreads), 0, st,
                                          N, s, t, ld, pos_out_ptr, pos_out_dst, pos_in_ptr, pos_in_src, Epos, neg_out_ptr, neg_out_dst,
-                                         neg_in_ptr, neg_in_src, Eneg, gscale, ds, dt));
+                                         neg_in_ptr, neg_in_src, Eneg, gscale, ds, dt, skip_pos_longer_than));
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_recon_heavy_lists(int H, const float* s, const float* t, int ld, int64_t Epos, const float* gscale, int K,
+                                     const int32_t* nodes, const int32_t* node_seg_ptr, int S, const int32_t* seg_node, const int32_t* seg_e0,
+                                     const int32_t* seg_e1, const int32_t* list, int which, float* partial_ws, float* out, void* stream) {
+    MGV_CHECK_ARG(K >= 0 && S >= 0 && Epos > 0 && s && t && gscale && out && ld >= H && ld % 4 == 0 && (which == 0 || which == 1));
+    if (K == 0 || S == 0) return MGV_OK;
+    MGV_CHECK_ARG(nodes && node_seg_ptr && seg_node && seg_e0 && seg_e1 && list && partial_ws);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    MGV_DISPATCH_H(H, hipLaunchKernelGGL((mgv::k_recon_heavy_seg<HH>), dim3(S < 4096 ? S : 4096), dim3(256), 0, st, S, seg_node, seg_e0, seg_e1, nodes,
+                                         s, t, ld, list, which, Epos, gscale, partial_ws));
+    hipLaunchKernelGGL(mgv::k_heavy_add, dim3((K + 15) / 16 < 1024 ? (K + 15) / 16 : 1024), dim3(256), 0, st, K, H, nodes, node_seg_ptr, partial_ws, out, ld, 1);
     MGV_LAUNCH_RET();
 }
 

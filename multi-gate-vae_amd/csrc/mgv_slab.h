@@ -49,4 +49,21 @@ static inline void launch_slab_sum(const T* slab, int nwg, int64_t stride, int n
     hipLaunchKernelGGL((k_slab_sum<T, O>), dim3((n + 63) / 64), dim3(1024), 0, st, slab, nwg, stride, n, out);
 }
 
+// out[nodes[k]][0..H) (+)= sum of the node's segment partials partial[seg][H] in segment order (heavy-list kernels: a node whose
+// list is too long for one lane group is cut into segments, one workgroup each)
+static __global__ __launch_bounds__(256) void k_heavy_add(int K, int H, const int32_t* nodes, const int32_t* node_seg_ptr, const float* partial,
+                                                          float* out, int ld, int accumulate) {
+    const int lpr = H / 4, lr = threadIdx.x % lpr;
+    for (int k = blockIdx.x * (256 / lpr) + threadIdx.x / lpr; k < K; k += gridDim.x * (256 / lpr)) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sg = node_seg_ptr[k]; sg < node_seg_ptr[k + 1]; ++sg) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)sg * H + 4 * lr);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(out + (int64_t)nodes[k] * ld + 4 * lr);
+        if (accumulate) { const float4 o = *dst; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+        *dst = s;
+    }
+}
+
 }  // namespace mgv

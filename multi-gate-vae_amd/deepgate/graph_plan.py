@@ -13,6 +13,8 @@ torch sorts / scans below.  Both give identical arrays.  It is batch constructio
 import ctypes
 import os
 
+import numpy as np
+
 import torch
 
 TILE = 64
@@ -128,6 +130,37 @@ class GraphPlan:
             nodes = torch.nonzero((p[1:] - p[:-1]) > self.HEAVY_ROW).reshape(-1).to(torch.int32)
             cache[reverse] = (int(nodes.numel()), nodes.contiguous())
         return cache[reverse]
+
+    HEAVY_SEG = 512     # list entries per workgroup of the heavy-list kernels
+
+    def heavy_segments(self, reverse, inactive_only=False):
+        """The heavy nodes' lists (see `heavy`) cut into segments of HEAVY_SEG entries for the per-node pull kernels whose
+        lists they are (reconstruction-loss backward over the positive edges, the sweep backward's pull of the never-updated
+        nodes): dict(K, nodes, node_seg_ptr[K+1], S, seg_node[S], seg_e0[S], seg_e1[S]) of int32 device arrays, or None when there
+        are none.  `inactive_only`: only nodes without an aggregator slot (needs set_levels)."""
+        cache = self.__dict__.setdefault('_heavy_seg', {})
+        key = (reverse, inactive_only)
+        if key not in cache:
+            K, nodes = self.heavy(reverse)
+            out = None
+            if K > 0:
+                if inactive_only:
+                    nodes = nodes[self.gslot[nodes.long()] == NO_GATE].contiguous()
+                    K = int(nodes.numel())
+            if K > 0:
+                p = self.csr(reverse)[0]
+                e0 = p[nodes.long()].cpu().numpy().astype(np.int64)
+                e1 = p[nodes.long() + 1].cpu().numpy().astype(np.int64)
+                seg_node, s0, s1, nsp = [], [], [], [0]
+                for k in range(K):
+                    for b in range(int(e0[k]), int(e1[k]), self.HEAVY_SEG):
+                        seg_node.append(k); s0.append(b); s1.append(min(b + self.HEAVY_SEG, int(e1[k])))
+                    nsp.append(len(seg_node))
+                i32 = dict(dtype=torch.int32, device=self.device)
+                out = dict(K=K, nodes=nodes, node_seg_ptr=torch.tensor(nsp, **i32), S=len(seg_node), seg_node=torch.tensor(seg_node, **i32),
+                           seg_e0=torch.tensor(s0, **i32), seg_e1=torch.tensor(s1, **i32))
+            cache[key] = out
+        return cache[key]
 
     def first_stage_classes(self, xcls, max_classes=256):
         """(degree, feature class) pairs of the forward CSR: every node enters the first half round of an encoder with

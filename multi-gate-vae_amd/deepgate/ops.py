@@ -469,12 +469,18 @@ class FuncSweepFn(torch.autograd.Function):
             # rows for the deferred weight gradient, small-gradient slabs of the widest level, 256 rows of weight-gradient partials
             scratch = torch.empty(plan.n_active * 5 * H + widest * T * 11 * H + 256 * 6 * H * H, dtype=F32, device=dev)
             stp = (_hip.ctypes.c_int32 * len(plan.slot_tile_ptr))(*plan.slot_tile_ptr)
+            hv = plan.heavy_segments(True, inactive_only=True)
             _hip.call('mgv_func_sweep_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.order_span),
                       plan.n_active, ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.slot_tiles), stp,
                       ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr), ptr(plan.out_dst), ptr(plan.out_slot),
                       ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]), ptr(ctx.wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]),
                       ptr(ghf), ptr(ghs), ptr(dzb), ptr(alpha), ptr(dsc), *[ptr(g) for g in grads], ptr(scratch),
-                      scratch.numel())
+                      scratch.numel(), plan.HEAVY_ROW if hv is not None else 0)
+            if hv is not None:
+                # primary inputs (never updated) that drive thousands of gates: their pull by whole workgroups, per list segment
+                pw = workspace(hv['S'] * H, dev)
+                _hip.call('mgv_sweep_pull_heavy', H, hv['K'], ptr(hv['nodes']), ptr(hv['node_seg_ptr']), hv['S'], ptr(hv['seg_e0']), ptr(hv['seg_e1']),
+                          ptr(plan.out_dst), ptr(plan.out_slot), ptr(plan.gslot), ptr(alpha), ptr(dsc), ptr(dzb), ptr(par[0]), ptr(pw), ptr(ghs))
             return (None, ghs, *grads)
         WvcT = par[1].transpose(1, 2).contiguous()
         _hip.call('mgv_func_sweep_bwd', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.tile_start),
@@ -574,9 +580,18 @@ class ReconLossFn(torch.autograd.Function):
         pl = ctx.plan
         if pl is not None and ctx.neg_csr is not None:
             dst_ = torch.empty_like(std)
+            # positive lists of high fan-out / fan-in nodes: skipped by the per-node pull, summed per segment by whole workgroups
+            heavy = [(0, pl.heavy_segments(True), pl.out_dst), (1, pl.heavy_segments(False), pl.in_src)]
+            skip = pl.HEAVY_ROW if any(hv is not None for _, hv, _ in heavy) else 0
             _hip.call('mgv_recon_loss_bwd_csr', H, std.shape[0], ptr(std), ptr(std[:, H:]), H2, ptr(pl.out_ptr), ptr(pl.out_dst),
                       ptr(pl.in_ptr), ptr(pl.in_src), ps.numel(), *[ptr(c) for c in ctx.neg_csr], ns.numel(), ptr(g), ptr(dst_),
-                      ptr(dst_[:, H:]))
+                      ptr(dst_[:, H:]), skip)
+            for which, hv, lst in heavy:
+                if hv is not None:
+                    pw = workspace(hv['S'] * H, std.device)
+                    _hip.call('mgv_recon_heavy_lists', H, ptr(std), ptr(std[:, H:]), H2, ps.numel(), ptr(g), hv['K'], ptr(hv['nodes']),
+                              ptr(hv['node_seg_ptr']), hv['S'], ptr(hv['seg_node']), ptr(hv['seg_e0']), ptr(hv['seg_e1']), ptr(lst), which,
+                              ptr(pw), ptr(dst_[:, H:]) if which else ptr(dst_))
             return dst_, None, None, None, None, None
         dst_ = torch.zeros_like(std)
         csr = (pl.out_ptr, pl.out_dst, pl.in_ptr, pl.in_src) if pl is not None else (None, None, None, None)
