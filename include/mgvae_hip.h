@@ -186,7 +186,13 @@ int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t
                           float* d_attn_u, float* dWvc, float* dbvc, float* dbih, float* dbhh, float* scratch,
                           int64_t scratch_elems,
                           int skip_inactive_longer_than /* > 0: never-updated nodes with more consumers are left to mgv_sweep_pull_heavy */,
-                          void* stream);
+                          /* updated gates with more than skip_active_longer_than consumers (an inverter of a clock-like input), ordered by
+                           * (level, id): nodes[K], node_seg_ptr[K+1], segment bounds, per-level ranges of nodes and segments as HOST arrays
+                           * [num_levels + 1] (GraphPlan.heavy_segments(True, active_by_level=True)); heavy_ws: (K + segments) * 2H floats.
+                           * Their pulls run per level by whole workgroups in front of the level's kernel.  0 / NULLs: none. */
+                          int heavy_active_n, const int32_t* heavy_nodes, const int32_t* heavy_node_seg_ptr, const int32_t* heavy_seg_e0,
+                          const int32_t* heavy_seg_e1, const int32_t* heavy_lvl_k_ptr_host, const int32_t* heavy_lvl_seg_ptr_host,
+                          float* heavy_ws, int skip_active_longer_than, void* stream);
 /* ghs rows of the heavy never-updated nodes (primary inputs driving thousands of gates): consumer lists in segments, one workgroup
  * each (GraphPlan.heavy_segments(reverse=True, inactive_only=True)); partial_ws: S * H floats */
 int mgv_sweep_pull_heavy(int H, int K, const int32_t* nodes, const int32_t* node_seg_ptr, int S, const int32_t* seg_e0,

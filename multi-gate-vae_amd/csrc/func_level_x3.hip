@@ -47,6 +47,9 @@ struct LevelX3Args {
     float* zrows;          // [n_active][2H] zbar rows in sweep order, for the weight-gradient kernel
     const int32_t* slot_tiles;   // tiles grouped by slot
     int skip_inactive;           // > 0: the inactive-node pull skips nodes with more consumers (mgv_sweep_pull_heavy writes their rows)
+    // updated gates with more than skip_active consumers (an inverter of a clock-like input): their pull comes from a per-level
+    // pre-pass (k_pull_heavy_seg<H, true>): heavy_nodes[heavy_k0 .. heavy_k1) = this level's, ascending ids; heavy_pull[k][2H]
+    int skip_active; int heavy_k0; int heavy_k1; const int32_t* heavy_nodes; const float* heavy_pull;
 };
 
 // kLW waves over a (64 rows) x COLS output: across column tiles first, then row tiles
@@ -474,7 +477,17 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
         const int row = grp + i * GROUPS;
         const int4 sp = ix.span[row];
         const int node = ix.node[row];
-        const int nout = min(sp.w - sp.z, kOutCap);
+        // a gate with a very long consumer list took its pull in this level's pre-pass (mgv_func_sweep_bwd_x3): look it up
+        int hk = -1;
+        if (a.heavy_k1 > a.heavy_k0 && sp.w - sp.z > a.skip_active) {
+            int lo = a.heavy_k0, hi = a.heavy_k1 - 1;
+            while (lo <= hi) {
+                const int mid = (lo + hi) >> 1, v = a.heavy_nodes[mid];
+                if (v == node) { hk = mid; break; }
+                if (v < node) lo = mid + 1; else hi = mid - 1;
+            }
+        }
+        const int nout = hk >= 0 ? 0 : min(sp.w - sp.z, kOutCap);
         InRows<H> L;
         OutRows<H> P;
         f32x4 own;
@@ -488,7 +501,12 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
             Q.issue(a, os, row * kOutCap, k0, nout, lr);
             Q.reduce(os, sv.uall, row * kOutCap, k0, nout, lr, gs, gf);
         }
-        pull_tail<H>(a, sp.z + kOutCap, sp.w, lr, gs, gf);
+        if (hk >= 0) {
+            gs = ld4(a.heavy_pull + (int64_t)hk * 2 * H + 4 * lr);
+            gf = ld4(a.heavy_pull + (int64_t)hk * 2 * H + H + 4 * lr);
+        } else {
+            pull_tail<H>(a, sp.z + kOutCap, sp.w, lr, gs, gf);
+        }
         float4 dh = zero4();
         if (node >= 0) dh = add4(gf, f4(own));
         if (i == 0) gs_keep[0] = gs; else gs_keep[1] = gs;
@@ -708,29 +726,33 @@ __global__ __launch_bounds__(kThreads) void k_level_pull_inactive_x3(LevelX3Args
 
 // One segment of a heavy never-updated node's consumer list per workgroup (a primary input that drives thousands of gates): the
 // hs-half of the pull, sum over consumers c of alpha_e dzb[c][:H] + dsc_e u_g(c)[:H]; 16 lane groups strided, LDS sum in group order.
-template <int H>
-__global__ __launch_bounds__(256) void k_pull_heavy_seg(int S, const int32_t* seg_e0, const int32_t* seg_e1, const int32_t* out_dst,
+template <int H, bool BOTH>
+__global__ __launch_bounds__(256) void k_pull_heavy_seg(int s0, int S, const int32_t* seg_e0, const int32_t* seg_e1, const int32_t* out_dst,
                                                         const int32_t* out_slot, const uint8_t* gslot, const float* alpha, const float* dsc,
                                                         const float* dzb, const float* attn_u, float* partial) {
-    constexpr int LPR = H / 4, G = 256 / LPR;
-    __shared__ __attribute__((aligned(16))) float s_p[G][H];
+    constexpr int LPR = H / 4, G = 256 / LPR, W = BOTH ? 2 * H : H;      // BOTH: the hs half and the hf half (an updated gate needs both)
+    __shared__ __attribute__((aligned(16))) float s_p[G][W];
     const int lr = threadIdx.x % LPR, grp = threadIdx.x / LPR;
-    for (int sg = blockIdx.x; sg < S; sg += gridDim.x) {
-        float4 gs = zero4();
+    for (int sg = s0 + blockIdx.x; sg < s0 + S; sg += gridDim.x) {
+        float4 gs = zero4(), gf = zero4();
         for (int e = seg_e0[sg] + grp; e < seg_e1[sg]; e += G) {
             const int64_t c = out_dst[e];
             const int gc = gslot[c];
             if (gc == kNoGateX) continue;
             const int sl = out_slot[e];
-            gs = fma4(alpha[sl], ld4(dzb + c * 2 * H + 4 * lr), fma4(dsc[sl], ld4(attn_u + (int64_t)gc * 2 * H + 4 * lr), gs));
+            const float al = alpha[sl], ds = dsc[sl];
+            gs = fma4(al, ld4(dzb + c * 2 * H + 4 * lr), fma4(ds, ld4(attn_u + (int64_t)gc * 2 * H + 4 * lr), gs));
+            if (BOTH) gf = fma4(al, ld4(dzb + c * 2 * H + H + 4 * lr), fma4(ds, ld4(attn_u + (int64_t)gc * 2 * H + H + 4 * lr), gf));
         }
         __syncthreads();
         st4(&s_p[grp][4 * lr], gs);
+        if (BOTH) st4(&s_p[grp][H + 4 * lr], gf);
         __syncthreads();
         if (grp == 0) {
-            float4 tot = zero4();
-            for (int g = 0; g < G; ++g) tot = add4(tot, ld4(&s_p[g][4 * lr]));
-            st4(partial + (int64_t)sg * H + 4 * lr, tot);
+            float4 tot = zero4(), tof = zero4();
+            for (int g = 0; g < G; ++g) { tot = add4(tot, ld4(&s_p[g][4 * lr])); if (BOTH) tof = add4(tof, ld4(&s_p[g][H + 4 * lr])); }
+            st4(partial + (int64_t)sg * W + 4 * lr, tot);
+            if (BOTH) st4(partial + (int64_t)sg * W + H + 4 * lr, tof);
         }
     }
 }
@@ -943,7 +965,10 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
                                      const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
                                      const float* bhh, const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc,
                                      float* d_attn_u, float* dWvc, float* dbvc, float* dbih, float* dbhh, float* scratch,
-                                     int64_t scratch_elems, int skip_inactive_longer_than, void* stream) {
+                                     int64_t scratch_elems, int skip_inactive_longer_than, int heavy_active_n,
+                                     const int32_t* heavy_nodes, const int32_t* heavy_node_seg_ptr, const int32_t* heavy_seg_e0,
+                                     const int32_t* heavy_seg_e1, const int32_t* heavy_lvl_k_ptr_host,
+                                     const int32_t* heavy_lvl_seg_ptr_host, float* heavy_ws, int skip_active_longer_than, void* stream) {
     MGV_CHECK_ARG(N >= 0 && T >= 1 && T <= mgv::kMaxSlots && num_levels >= 0 && n_active >= 0 && level_tile_ptr_host && hs && hf &&
                   attn_u && wpack_bf16 && bvc && bih && bhh);
     MGV_CHECK_ARG(in_ptr && out_ptr && gslot && ghf && ghs && dzb && d_attn_u && dWvc && dbvc && dbih && dbhh);
@@ -956,6 +981,9 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
     a.out_ptr = out_ptr; a.out_dst = out_dst; a.out_slot = out_slot; a.gslot = gslot;
     a.ghf = ghf; a.ghs = ghs; a.dzb = dzb; a.alpha = alpha; a.dsc = dsc; a.d_attn_u = d_attn_u; a.dWvc = dWvc; a.dbvc = dbvc;
     a.dbih = dbih; a.dbhh = dbhh; a.skip_inactive = skip_inactive_longer_than;
+    MGV_CHECK_ARG(heavy_active_n >= 0 && (heavy_active_n == 0 || (heavy_nodes && heavy_node_seg_ptr && heavy_seg_e0 && heavy_seg_e1 &&
+                                                                heavy_lvl_k_ptr_host && heavy_lvl_seg_ptr_host && heavy_ws && skip_active_longer_than > 0)));
+    a.skip_active = skip_active_longer_than; a.heavy_nodes = heavy_nodes; a.heavy_pull = heavy_ws;      // [K][2H], then the segment partials
     hipStream_t st = static_cast<hipStream_t>(stream);
     int nslab = 0;
     for (int lv = 1; lv < num_levels; ++lv) nslab = std::max(nslab, level_tile_ptr_host[lv + 1] - level_tile_ptr_host[lv]);
@@ -973,6 +1001,18 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
         if (t1 <= t0) continue;
         MGV_CHECK_ARG(order && order_span && tile_start && tile_count && tile_slot && in_src && out_dst && out_slot && alpha && dsc);
         a.tile_begin = t0;
+        a.heavy_k0 = a.heavy_k1 = 0;
+        if (heavy_active_n > 0 && heavy_lvl_k_ptr_host[lv + 1] > heavy_lvl_k_ptr_host[lv]) {
+            // this level's gates with very long consumer lists: their pulls by whole workgroups, one per list segment, before the level kernel
+            const int k0 = heavy_lvl_k_ptr_host[lv], k1 = heavy_lvl_k_ptr_host[lv + 1];
+            const int s0 = heavy_lvl_seg_ptr_host[lv], s1 = heavy_lvl_seg_ptr_host[lv + 1];
+            float* partial = heavy_ws + (int64_t)heavy_active_n * 2 * H;
+            const int grid = (s1 - s0) < 4096 ? (s1 - s0) : 4096;
+            if (H == 32) hipLaunchKernelGGL((mgv::k_pull_heavy_seg<32, true>), dim3(grid), dim3(256), 0, st, s0, s1 - s0, heavy_seg_e0, heavy_seg_e1, out_dst, out_slot, gslot, alpha, dsc, dzb, attn_u, partial);
+            else hipLaunchKernelGGL((mgv::k_pull_heavy_seg<64, true>), dim3(grid), dim3(256), 0, st, s0, s1 - s0, heavy_seg_e0, heavy_seg_e1, out_dst, out_slot, gslot, alpha, dsc, dzb, attn_u, partial);
+            hipLaunchKernelGGL(mgv::k_heavy_add_range, dim3(((k1 - k0) * 2 + 15) / 16), dim3(256), 0, st, k0, k1, 2 * H, heavy_node_seg_ptr, partial, heavy_ws);
+            a.heavy_k0 = k0; a.heavy_k1 = k1;
+        }
         int rc;
         switch (H) {
             case 32: rc = mgv::launch_level_x3<32>(true, a, t1 - t0, st); break;
@@ -1017,8 +1057,8 @@ extern "C" int mgv_sweep_pull_heavy(int H, int K, const int32_t* nodes, const in
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int grid = S < 4096 ? S : 4096;
     switch (H) {
-        case 32: hipLaunchKernelGGL(mgv::k_pull_heavy_seg<32>, dim3(grid), dim3(256), 0, st, S, seg_e0, seg_e1, out_dst, out_slot, gslot, alpha, dsc, dzb, attn_u, partial_ws); break;
-        case 64: hipLaunchKernelGGL(mgv::k_pull_heavy_seg<64>, dim3(grid), dim3(256), 0, st, S, seg_e0, seg_e1, out_dst, out_slot, gslot, alpha, dsc, dzb, attn_u, partial_ws); break;
+        case 32: hipLaunchKernelGGL((mgv::k_pull_heavy_seg<32, false>), dim3(grid), dim3(256), 0, st, 0, S, seg_e0, seg_e1, out_dst, out_slot, gslot, alpha, dsc, dzb, attn_u, partial_ws); break;
+        case 64: hipLaunchKernelGGL((mgv::k_pull_heavy_seg<64, false>), dim3(grid), dim3(256), 0, st, 0, S, seg_e0, seg_e1, out_dst, out_slot, gslot, alpha, dsc, dzb, attn_u, partial_ws); break;
         default: return MGV_EUNSUPPORTED;
     }
     hipLaunchKernelGGL(mgv::k_heavy_add, dim3((K + 15) / 16 < 1024 ? (K + 15) / 16 : 1024), dim3(256), 0, st, K, H, nodes, node_seg_ptr, partial_ws, ghs, H, 0);

@@ -66,4 +66,17 @@ static __global__ __launch_bounds__(256) void k_heavy_add(int K, int H, const in
     }
 }
 
+// out[k][0..W) = sum of node k's segment partials (k in [k0, k1): rows indexed by k, not by node id)
+static __global__ __launch_bounds__(256) void k_heavy_add_range(int k0, int k1, int W, const int32_t* node_seg_ptr, const float* partial, float* out) {
+    const int lpr = W / 4, lr = threadIdx.x % lpr;
+    for (int k = k0 + blockIdx.x * (256 / lpr) + threadIdx.x / lpr; k < k1; k += gridDim.x * (256 / lpr)) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sg = node_seg_ptr[k]; sg < node_seg_ptr[k + 1]; ++sg) {
+            const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)sg * W + 4 * lr);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + (int64_t)k * W + 4 * lr) = s;
+    }
+}
+
 }  // namespace mgv

@@ -133,20 +133,28 @@ class GraphPlan:
 
     HEAVY_SEG = 512     # list entries per workgroup of the heavy-list kernels
 
-    def heavy_segments(self, reverse, inactive_only=False):
+    def heavy_segments(self, reverse, inactive_only=False, active_by_level=False):
         """The heavy nodes' lists (see `heavy`) cut into segments of HEAVY_SEG entries for the per-node pull kernels whose
-        lists they are (reconstruction-loss backward over the positive edges, the sweep backward's pull of the never-updated
-        nodes): dict(K, nodes, node_seg_ptr[K+1], S, seg_node[S], seg_e0[S], seg_e1[S]) of int32 device arrays, or None when there
-        are none.  `inactive_only`: only nodes without an aggregator slot (needs set_levels)."""
+        lists they are (reconstruction-loss backward over the positive edges, the sweep backward's pulls):
+        dict(K, nodes, node_seg_ptr[K+1], S, seg_node[S], seg_e0[S], seg_e1[S]) of int32 device arrays, or None when there
+        are none.  `inactive_only`: only nodes without an aggregator slot; `active_by_level`: only nodes WITH one, ordered by
+        (level, id), plus host lists lvl_k_ptr / lvl_seg_ptr [num_levels + 1] (the nodes / segments of each level); both need
+        set_levels."""
         cache = self.__dict__.setdefault('_heavy_seg', {})
-        key = (reverse, inactive_only)
+        key = (reverse, inactive_only, active_by_level)
         if key not in cache:
             K, nodes = self.heavy(reverse)
             out = None
-            if K > 0:
-                if inactive_only:
-                    nodes = nodes[self.gslot[nodes.long()] == NO_GATE].contiguous()
-                    K = int(nodes.numel())
+            lv = None
+            if K > 0 and (inactive_only or active_by_level):
+                act = self.gslot[nodes.long()] != NO_GATE
+                nodes = nodes[act if active_by_level else ~act].contiguous()
+                K = int(nodes.numel())
+                if K > 0 and active_by_level:
+                    lv_dev = self.level[nodes.long()].long()
+                    order = torch.sort(lv_dev * (self.N + 1) + nodes.long()).indices          # by (level, id)
+                    nodes = nodes[order].contiguous()
+                    lv = lv_dev[order].cpu().numpy()
             if K > 0:
                 p = self.csr(reverse)[0]
                 e0 = p[nodes.long()].cpu().numpy().astype(np.int64)
@@ -159,6 +167,12 @@ class GraphPlan:
                 i32 = dict(dtype=torch.int32, device=self.device)
                 out = dict(K=K, nodes=nodes, node_seg_ptr=torch.tensor(nsp, **i32), S=len(seg_node), seg_node=torch.tensor(seg_node, **i32),
                            seg_e0=torch.tensor(s0, **i32), seg_e1=torch.tensor(s1, **i32))
+                if lv is not None:
+                    L = max(self.num_levels, 1)
+                    cnt = np.bincount(lv, minlength=L)
+                    kp = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+                    out['lvl_k_ptr'] = [int(v) for v in kp]
+                    out['lvl_seg_ptr'] = [int(nsp[int(v)]) for v in kp]
             cache[key] = out
         return cache[key]
 

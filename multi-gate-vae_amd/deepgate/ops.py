@@ -470,12 +470,24 @@ class FuncSweepFn(torch.autograd.Function):
             scratch = torch.empty(plan.n_active * 5 * H + widest * T * 11 * H + 256 * 6 * H * H, dtype=F32, device=dev)
             stp = (_hip.ctypes.c_int32 * len(plan.slot_tile_ptr))(*plan.slot_tile_ptr)
             hv = plan.heavy_segments(True, inactive_only=True)
+            hav = plan.heavy_segments(True, active_by_level=True)      # updated gates with very long consumer lists
+            if hav is None:
+                ha = (0, None, None, None, None, None, None, None, 0)
+            else:
+                i32a = _hip.ctypes.c_int32
+                kp = (i32a * len(hav['lvl_k_ptr']))(*hav['lvl_k_ptr'])
+                sp_ = (i32a * len(hav['lvl_seg_ptr']))(*hav['lvl_seg_ptr'])
+                need = (hav['K'] + hav['S']) * 2 * H          # its own buffer: it must outlive the launcher call's other scratch users
+                hws = _WS.get(('heavy_active', str(dev)))
+                if hws is None or hws.numel() < need:
+                    hws = _WS[('heavy_active', str(dev))] = torch.empty(need, dtype=F32, device=dev)
+                ha = (hav['K'], ptr(hav['nodes']), ptr(hav['node_seg_ptr']), ptr(hav['seg_e0']), ptr(hav['seg_e1']), kp, sp_, ptr(hws), plan.HEAVY_ROW)
             _hip.call('mgv_func_sweep_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.order_span),
                       plan.n_active, ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.slot_tiles), stp,
                       ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr), ptr(plan.out_dst), ptr(plan.out_slot),
                       ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]), ptr(ctx.wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]),
                       ptr(ghf), ptr(ghs), ptr(dzb), ptr(alpha), ptr(dsc), *[ptr(g) for g in grads], ptr(scratch),
-                      scratch.numel(), plan.HEAVY_ROW if hv is not None else 0)
+                      scratch.numel(), plan.HEAVY_ROW if hv is not None else 0, *ha)
             if hv is not None:
                 # primary inputs (never updated) that drive thousands of gates: their pull by whole workgroups, per list segment
                 pw = workspace(hv['S'] * H, dev)

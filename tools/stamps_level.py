@@ -69,7 +69,7 @@ def main():
         H, ctypes.c_int64(N), T, plan.num_levels, ltp, P(plan.order), P(plan.order_span), ctypes.c_int64(plan.n_active),
         P(plan.tile_start), P(plan.tile_count), P(plan.tile_slot), P(plan.slot_tiles), stp, P(plan.in_ptr), P(plan.in_src),
         P(plan.out_ptr), P(plan.out_dst), P(plan.out_slot), P(plan.gslot), P(hs), P(hf), P(attn_u), P(wpack), P(bvc), P(bih), P(bhh),
-        P(ghf), P(ghs), P(dzb), P(alpha), P(dsc), *[P(g) for g in grads], P(scratch), ctypes.c_int64(scratch.numel()), 0, st)
+        P(ghf), P(ghs), P(dzb), P(alpha), P(dsc), *[P(g) for g in grads], P(scratch), ctypes.c_int64(scratch.numel()), 0, 0, None, None, None, None, None, None, None, 0, st)
     torch.cuda.synchronize()
     assert rc == 0, rc
     t = stamps.view(8, 16).double().cpu()
