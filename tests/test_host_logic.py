@@ -183,3 +183,48 @@ def test_two_rank_gradient_exchange_is_the_mean_of_shard_gradients(tmp_path):
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'EXCHANGE_OK' in out.stdout
+
+
+def test_heavy_lists_and_segments_cover_the_long_lists_exactly(monkeypatch):
+    """GraphPlan.heavy / heavy_segments (the lists taken out of the per-node kernels): with the thresholds lowered, every list
+    longer than HEAVY_ROW is listed once, its segments tile [ptr[n], ptr[n+1]) in order, never-updated and updated nodes split as
+    asked, and the updated ones come grouped by level."""
+    import numpy as np
+    import torch
+    import deepgate
+    from deepgate import synthetic as syn
+    from deepgate.graph_plan import GraphPlan
+    monkeypatch.setattr(GraphPlan, 'HEAVY_ROW', 2)
+    monkeypatch.setattr(GraphPlan, 'HEAVY_SEG', 3)
+    arrays = syn.collate([syn.make_graph('aig', 122, 7, 40 + i, n_inputs=10) for i in range(2)])
+    N = arrays['num_nodes']
+    plan = GraphPlan(torch.from_numpy(arrays['edge_index']), N)
+    plan.set_levels(torch.from_numpy(arrays['gate']), torch.from_numpy(arrays['forward_level']), [1, 2])
+    for rev in (False, True):
+        ptr = plan.csr(rev)[0].numpy()
+        deg = np.diff(ptr)
+        K, nodes = plan.heavy(rev)
+        assert K == int((deg > 2).sum()) and np.array_equal(nodes.numpy(), np.nonzero(deg > 2)[0])
+        for kw in ({}, {'inactive_only': True}, {'active_by_level': True}):
+            hv = plan.heavy_segments(rev, **kw)
+            gs = plan.gslot.numpy()
+            want = [n for n in np.nonzero(deg > 2)[0] if not kw or (gs[n] == 255) == ('inactive_only' in kw)]
+            if not want:
+                assert hv is None
+                continue
+            got = hv['nodes'].numpy().tolist()
+            assert sorted(got) == sorted(want) and hv['K'] == len(want)
+            nsp, e0, e1, sn = (hv[k].numpy() for k in ('node_seg_ptr', 'seg_e0', 'seg_e1', 'seg_node'))
+            for k, n in enumerate(got):
+                segs = range(nsp[k], nsp[k + 1])
+                assert all(sn[s] == k for s in segs)
+                assert e0[nsp[k]] == ptr[n] and e1[nsp[k + 1] - 1] == ptr[n + 1]
+                assert all(e1[s] == e0[s + 1] for s in list(segs)[:-1]) and all(0 < e1[s] - e0[s] <= 3 for s in segs)
+            if 'active_by_level' in kw:
+                lv = plan.level.numpy()[got]
+                assert np.all(np.diff(lv) >= 0)
+                kp, sp = hv['lvl_k_ptr'], hv['lvl_seg_ptr']
+                assert len(kp) == plan.num_levels + 1 and kp[-1] == hv['K'] and sp[-1] == hv['S']
+                for level in range(plan.num_levels):
+                    assert all(lv[k] == level for k in range(kp[level], kp[level + 1]))
+                    assert sp[level] == nsp[kp[level]]
