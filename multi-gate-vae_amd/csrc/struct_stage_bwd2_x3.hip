@@ -235,15 +235,16 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                 const int t = tid & 127;
                 int64_t row = nb + (t >> 1);
                 row = row < a.N ? row : a.N - 1;
-                pf0 = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(row * (H * 4)) + 128u * (t & 1), 0, 0);     // default cache policy: the line must stay in L2
+                if (w >= 2 || a.hshift == 0)        // (table mode: h_in is the small class table, nothing to prefetch and N rows are not behind it)
+                    pf0 = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(row * (H * 4)) + 128u * (t & 1), 0, 0);     // default cache policy: the line must stay in L2
                 if (two && tid < ne2) {
                     const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy_agg), 0, nbytes, 0x00020000);
-                    pf1 = __builtin_amdgcn_raw_buffer_load_b32(rg, (unsigned)n_idx[tid >> 1] * (H * 4) + 128u * (tid & 1), 0, 0);
+                    pf1 = __builtin_amdgcn_raw_buffer_load_b32(rg, (unsigned)(n_idx[tid >> 1] & a.gmask) * (H * 4) + 128u * (tid & 1), 0, 0);
                 }
             } else {
                 const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.h_in), 0, nbytes, 0x00020000);
                 const int t = tid - 256;
-                if (t < ne2) pf0 = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)n_idx[t >> 1] * (H * 4) + 128u * (t & 1), 0, 0);
+                if (t < ne2 && a.hshift == 0) pf0 = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)n_idx[t >> 1] * (H * 4) + 128u * (t & 1), 0, 0);
             }
         }
         // ---- P2. GRU forward values of row tiles 2m, 2m+1 and LayerNorm partials over this wave's 16 columns.  Written on 4-vectors
@@ -564,7 +565,7 @@ extern "C" int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, con
                                         const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
                                         float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
                                         float* dln_b, float* workspace, int64_t workspace_floats, int heavy_n,
-                                        const int32_t* heavy_nodes, float* heavy_ws, void* stream) {
+                                        const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx, void* stream) {
     MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && gy_direct);
     MGV_CHECK_ARG(dWc && dbc && dWhh && dbhh && dxtab);
     MGV_CHECK_ARG(C >= 1 && C <= mgv::kMaxClsX3);
@@ -579,6 +580,9 @@ extern "C" int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, con
     a.wpack = static_cast<const __bf16*>(wpack_bf16); a.bc = bc; a.bhh = bhh; a.lnw = ln_w; a.lnb = ln_b; a.eps = ln_eps;
     a.gy_direct = gy_direct; a.gy_agg = gy_agg; a.g_direct_out = g_direct_out; a.g_agg_out = g_agg_out;
     a.dWc = dWc; a.dbc = dbc; a.dWhh = dWhh; a.dbhh = dbhh; a.dxtab = dxtab; a.dlnw = dln_w; a.dlnb = dln_b;
+    a.gmask = -1;
+    MGV_CHECK_ARG(table_own_idx == nullptr || N < (1 << 24));
+    if (table_own_idx) { a.hshift = 24; a.gmask = 0xffffff; a.own_idx = table_own_idx; }
     MGV_SET_STAMPS2(a);
     { static const int v = [] { const char* e = getenv("MGV_XCD_TILES"); return (e && e[0] == '0') ? 0 : 1; }(); a.xcd = v; }
     { static const int v = [] { const char* e = getenv("MGV_ROW_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }(); a.prefetch = v; }

@@ -33,6 +33,9 @@ struct StageX3Args {
     // rows with more than kHeavyRow neighbours (a clock/reset-like net), ascending node ids, and their neighbour sums formed by
     // k_heavy_sums before the stage kernel starts: [heavy_n][H] over h_in, then [heavy_n][H] over gy_agg (backward only)
     int heavy_n; const int32_t* heavy_nodes; const float* heavy_a; const float* heavy_g;
+    // table mode (the half round after the (degree, class)-table one): h_in is the C-row table, a neighbour entry carries its class in
+    // the top byte (h row = entry >> 24, gradient row = entry & 0xffffff), a node's own h row is own_idx[node].  Normal mode: 0 / ~0 / NULL.
+    int hshift; int gmask; const int32_t* own_idx;
 };
 
 #include "mgv_stamps.h"
@@ -225,7 +228,7 @@ __device__ __forceinline__ void rows_chunked(const StageX3Args& a, int64_t base,
 #pragma unroll
     for (int rr = 0; rr < RPG; ++rr) {
         const int64_t node = base + grp + rr * groups;
-        own[rr] = ld4(a.h_in + node * H + 4 * lr);
+        own[rr] = ld4(a.h_in + (a.own_idx ? (int64_t)a.own_idx[node] : node) * H + 4 * lr);
         if (DY) dy[rr] = ld4(a.gy_direct + node * H + 4 * lr); else dy[rr] = zero4();
         cls[rr] = a.xcls[node];
         // predicated loads into registers that are NOT written on the untaken path (a zero-initialised
@@ -233,8 +236,8 @@ __device__ __forceinline__ void rows_chunked(const StageX3Args& a, int64_t base,
 #pragma unroll
         for (int k = 0; k < D; ++k)
             if (k < d[rr]) {
-                v0[rr][k] = *reinterpret_cast<const f32x4*>(a.h_in + (int64_t)j0[rr][k] * H + 4 * lr);
-                if (DY && two) g0[rr][k] = *reinterpret_cast<const f32x4*>(a.gy_agg + (int64_t)j0[rr][k] * H + 4 * lr);
+                v0[rr][k] = *reinterpret_cast<const f32x4*>(a.h_in + (int64_t)((unsigned)j0[rr][k] >> a.hshift) * H + 4 * lr);
+                if (DY && two) g0[rr][k] = *reinterpret_cast<const f32x4*>(a.gy_agg + (int64_t)(j0[rr][k] & a.gmask) * H + 4 * lr);
             }
     }
 #pragma unroll
@@ -260,8 +263,8 @@ __device__ __forceinline__ void rows_chunked(const StageX3Args& a, int64_t base,
 #pragma unroll
             for (int k = 0; k < D; ++k)
                 if (c0 + k < d[rr]) {
-                    v[rr][k] = *reinterpret_cast<const f32x4*>(a.h_in + (int64_t)j[rr][k] * H + 4 * lr);
-                    if (DY && two) g[rr][k] = *reinterpret_cast<const f32x4*>(a.gy_agg + (int64_t)j[rr][k] * H + 4 * lr);
+                    v[rr][k] = *reinterpret_cast<const f32x4*>(a.h_in + (int64_t)((unsigned)j[rr][k] >> a.hshift) * H + 4 * lr);
+                    if (DY && two) g[rr][k] = *reinterpret_cast<const f32x4*>(a.gy_agg + (int64_t)(j[rr][k] & a.gmask) * H + 4 * lr);
                 }
 #pragma unroll
         for (int rr = 0; rr < RPG; ++rr)
@@ -286,7 +289,7 @@ __device__ __forceinline__ void row_generic(const StageX3Args& a, int64_t node, 
     if (node >= a.N) return;
     const int p0 = s_ptr[row], p1 = s_ptr[row + 1];
     deg = (float)(p1 - p0);
-    own = ld4(a.h_in + node * H + 4 * lr);
+    own = ld4(a.h_in + (a.own_idx ? (int64_t)a.own_idx[node] : node) * H + 4 * lr);
     if (DY) dy = ld4(a.gy_direct + node * H + 4 * lr);
     cls = a.xcls[node];
     if (p1 - p0 > kHeavyRow && a.heavy_n > 0) {
@@ -303,9 +306,9 @@ __device__ __forceinline__ void row_generic(const StageX3Args& a, int64_t node, 
         }
     }
     for (int e = p0; e < p1; ++e) {
-        const int64_t jj = a.idx[e];
-        acc = add4(acc, ld4(a.h_in + jj * H + 4 * lr));
-        if (DY && two) dy = add4(dy, ld4(a.gy_agg + jj * H + 4 * lr));
+        const int jv = a.idx[e];
+        acc = add4(acc, ld4(a.h_in + (int64_t)((unsigned)jv >> a.hshift) * H + 4 * lr));
+        if (DY && two) dy = add4(dy, ld4(a.gy_agg + (int64_t)(jv & a.gmask) * H + 4 * lr));
     }
 }
 
@@ -314,7 +317,7 @@ __device__ __forceinline__ void row_generic(const StageX3Args& a, int64_t node, 
 // gy_agg[nbr] (gy_agg nullable).
 template <int H>
 static __global__ __launch_bounds__(256) void k_heavy_sums(int K, const int32_t* nodes, const int32_t* ptr, const int32_t* idx,
-                                                           const float* src_a, const float* src_g, float* out_a, float* out_g) {
+                                                           const float* src_a, const float* src_g, float* out_a, float* out_g, int hshift, int gmask) {
     constexpr int LPR = H / 4, G = 256 / LPR;
     __shared__ __attribute__((aligned(16))) float s_p[2][G][H];
     const int lr = threadIdx.x % LPR, grp = threadIdx.x / LPR;
@@ -324,14 +327,14 @@ static __global__ __launch_bounds__(256) void k_heavy_sums(int K, const int32_t*
         float4 sa = zero4(), sg = zero4();
         int e = p0 + grp;
         for (; e + 3 * G < p1; e += 4 * G) {
-            int64_t j[4];
+            int j[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) j[u] = idx[e + u * G];
             float4 va[4], vg[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                va[u] = ld4(src_a + j[u] * H + 4 * lr);
-                if (src_g) vg[u] = ld4(src_g + j[u] * H + 4 * lr);
+                va[u] = ld4(src_a + (int64_t)((unsigned)j[u] >> hshift) * H + 4 * lr);
+                if (src_g) vg[u] = ld4(src_g + (int64_t)(j[u] & gmask) * H + 4 * lr);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -340,9 +343,9 @@ static __global__ __launch_bounds__(256) void k_heavy_sums(int K, const int32_t*
             }
         }
         for (; e < p1; e += G) {
-            const int64_t jj = idx[e];
-            sa = add4(sa, ld4(src_a + jj * H + 4 * lr));
-            if (src_g) sg = add4(sg, ld4(src_g + jj * H + 4 * lr));
+            const int jv = idx[e];
+            sa = add4(sa, ld4(src_a + (int64_t)((unsigned)jv >> hshift) * H + 4 * lr));
+            if (src_g) sg = add4(sg, ld4(src_g + (int64_t)(jv & gmask) * H + 4 * lr));
         }
         __syncthreads();
         st4(&s_p[0][grp][4 * lr], sa);
@@ -365,7 +368,7 @@ static inline void launch_heavy_sums(StageX3Args& a, int heavy_n, const int32_t*
     float* out_a = ws;
     float* out_g = ws + (int64_t)heavy_n * H;
     const float* src_g = with_g ? a.gy_agg : nullptr;
-    hipLaunchKernelGGL(k_heavy_sums<H>, dim3(heavy_n < 1024 ? heavy_n : 1024), dim3(256), 0, st, heavy_n, heavy_nodes, a.ptr, a.idx, a.h_in, src_g, out_a, out_g);
+    hipLaunchKernelGGL(k_heavy_sums<H>, dim3(heavy_n < 1024 ? heavy_n : 1024), dim3(256), 0, st, heavy_n, heavy_nodes, a.ptr, a.idx, a.h_in, src_g, out_a, out_g, a.hshift, a.gmask);
     a.heavy_n = heavy_n; a.heavy_nodes = heavy_nodes; a.heavy_a = out_a; a.heavy_g = out_g;
 }
 

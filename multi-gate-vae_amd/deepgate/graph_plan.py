@@ -118,6 +118,16 @@ class GraphPlan:
         edges are flipped (`r_edge_index`, digae_layer.py:264)."""
         return (self.out_ptr, self.out_dst) if reverse else (self.in_ptr, self.in_src)
 
+    def tagged_idx(self, reverse, class_id):
+        """The neighbour array of `csr(reverse)` with each neighbour's (degree, class) table row in the top byte (entry = node | row << 24):
+        what the struct-stage kernels read in table mode.  Cached per direction and class-id tensor."""
+        cache = self.__dict__.setdefault('_tagged', {})
+        key = (reverse, class_id.data_ptr())
+        if key not in cache:
+            idx = self.csr(reverse)[1]
+            cache[key] = (idx | (class_id[idx.long()] << 24)).to(torch.int32).contiguous()
+        return cache[key]
+
     HEAVY_ROW = 64      # csrc/struct_stage_x3_common.h: kHeavyRow
 
     def heavy(self, reverse):

@@ -97,20 +97,24 @@ def _heavy_args(heavy, H, device):
     return n, ptr(nodes), ptr(hw)
 
 
-def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, out=None, wpack=None, heavy=None):
+def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, out=None, wpack=None, heavy=None, table_own=None):
+    """`table_own` (int32 [N]): table mode — h_in is the (degree, class) table, nbr_idx entries are tagged (GraphPlan.tagged_idx)."""
     N, H = h_in.shape
+    if table_own is not None:
+        N = table_own.numel()
     check(h_in, F32, 'h_in'); check(nbr_ptr, I32, 'nbr_ptr'); check(nbr_idx, I32, 'nbr_idx'); check(xcls, U8, 'xcls')
     for n, t in (('xtab', xtab), ('Wc', Wc), ('bc', bc), ('Whh', Whh), ('bhh', bhh)):
         check(t, F32, n)
     check(ln_w, F32, 'ln_w'); check(ln_b, F32, 'ln_b')
     assert nbr_ptr.numel() == N + 1 and xcls.numel() == N
     assert Wc.shape == (3 * H, H) and Whh.shape == (3 * H, H) and xtab.shape[1] == 3 * H
-    h_out = torch.empty_like(h_in) if out is None else out
+    h_out = (torch.empty(N, H, dtype=F32, device=h_in.device) if out is None else out)
     if use_x3(H):
         wpack = stage_wpack(Wc, Whh) if wpack is None else wpack
         _hip.call('mgv_struct_stage_fwd_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
-                  xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(h_out), *_heavy_args(heavy, H, h_in.device))
+                  xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(h_out), *_heavy_args(heavy, H, h_in.device), ptr(table_own))
         return h_out
+    assert table_own is None, 'table mode needs the bf16x3 kernels'
     _hip.call('mgv_struct_stage_fwd', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
               xtab.shape[0], ptr(Wc), ptr(bc), ptr(Whh), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(h_out))
     return h_out
@@ -119,6 +123,7 @@ def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
 # backward kernel of the bf16x3 half round at H = 64: '2' = register-resident recompute weights, transposed products,
 # slab-reduced (deterministic) parameter gradients (struct_stage_bwd2_x3.hip); '1' = the first kernel (A/B measurements)
 STAGE_BWD = os.environ.get('MGV_STAGE_BWD', '2')
+TABLE_MODE = os.environ.get('MGV_TABLE_MODE', '1') != '0'     # half round 2 of an encoder reads the (degree, class) table directly
 _WS = {}
 
 
@@ -151,21 +156,24 @@ def _stage_ws(H, N, device):
 
 
 def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, gy_direct, gy_agg,
-                     grads, need_input_grad=True, wpack=None, heavy=None):
+                     grads, need_input_grad=True, wpack=None, heavy=None, table_own=None):
     """`grads` = dict of fp32 accumulators (dWc, dbc, dWhh, dbhh, dxtab, dln_w, dln_b), added to."""
     N, H = h_in.shape
+    if table_own is not None:
+        N = table_own.numel()
     check(gy_direct, F32, 'gy_direct'); check(gy_agg, F32, 'gy_agg')
     if use_x3(H) and H == 64 and STAGE_BWD == '2':
-        g_direct = torch.empty_like(h_in) if need_input_grad else None
-        g_agg = torch.empty_like(h_in) if need_input_grad else None
+        g_direct = torch.empty(N, H, dtype=F32, device=h_in.device) if need_input_grad else None
+        g_agg = torch.empty(N, H, dtype=F32, device=h_in.device) if need_input_grad else None
         wpack = stage_wpack(Wc, Whh) if wpack is None else wpack
         ws = _stage_ws(H, N, h_in.device)
         _hip.call('mgv_struct_stage_bwd2_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
                   xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(gy_direct),
                   ptr(gy_agg), ptr(g_direct), ptr(g_agg), ptr(grads['dWc']), ptr(grads['dbc']), ptr(grads['dWhh']),
                   ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')),
-                  ptr(ws), ws.numel(), *_heavy_args(heavy, H, h_in.device))
+                  ptr(ws), ws.numel(), *_heavy_args(heavy, H, h_in.device), ptr(table_own))
         return g_direct, g_agg
+    assert table_own is None, 'table mode needs the H = 64 bf16x3 backward'
     if use_x3(H):
         g_direct = torch.empty_like(h_in) if need_input_grad else None
         g_agg = torch.empty_like(h_in) if need_input_grad else None
@@ -173,7 +181,7 @@ def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
         _hip.call('mgv_struct_stage_bwd_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
                   xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(gy_direct),
                   ptr(gy_agg), ptr(g_direct), ptr(g_agg), ptr(grads['dWc']), ptr(grads['dbc']), ptr(grads['dWhh']),
-                  ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')), *_heavy_args(heavy, H, h_in.device))
+                  ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')), *_heavy_args(heavy, H, h_in.device), None)
         return g_direct, g_agg
     WcT = Wc.t().contiguous()
     WhhT = Whh.t().contiguous()
@@ -209,6 +217,8 @@ class StructEncoderFn(torch.autograd.Function):
         # (degree, feature class) pair does for all nodes of the pair
         first = plan.first_stage_classes(xcls) if (FIRST_STAGE_TABLE and rounds > 0 and N > 0) else None
         h = None if first is not None else torch.ones(N, H, dtype=F32, device=dev)
+        # table mode for the half round after the table one: bf16x3 H = 64 kernels, node ids and table rows fit a tagged 32-bit entry
+        table_mode = first is not None and use_x3(H) and H == 64 and STAGE_BWD == '2' and N < (1 << 24) and first[1] <= 256 and TABLE_MODE
         states = []
         for _ in range(rounds):
             for rev in (False, True):
@@ -219,8 +229,14 @@ class StructEncoderFn(torch.autograd.Function):
                     cid, C, tp, ti, tx = first
                     table = struct_stage_fwd(torch.ones(C, H, dtype=F32, device=dev), tp, ti, tx, w[0], w[1], w[2], w[3], w[4],
                                              lw, lb, wpack=packs[0])
-                    h = torch.empty(N, H, dtype=F32, device=dev)
-                    _hip.call('mgv_class_expand', H, N, ptr(table), ptr(cid), ptr(h))
+                    if table_mode:
+                        h = ('table', table)     # never expanded to N rows: the next half round reads the table through tagged entries
+                    else:
+                        h = torch.empty(N, H, dtype=F32, device=dev)
+                        _hip.call('mgv_class_expand', H, N, ptr(table), ptr(cid), ptr(h))
+                elif isinstance(h, tuple):
+                    h = struct_stage_fwd(h[1], p, plan.tagged_idx(rev, first[0]), xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)],
+                                         heavy=plan.heavy(rev), table_own=first[0])
                 else:
                     h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)], heavy=plan.heavy(rev))
         ctx.plan, ctx.xcls, ctx.rounds, ctx.packs, ctx.first = plan, xcls, rounds, packs, first
@@ -255,6 +271,10 @@ class StructEncoderFn(torch.autograd.Function):
                     _hip.call('mgv_class_pull_sum', H, plan.N, ptr(g_direct), ptr(g_agg), ptr(p), ptr(i), ptr(cid), C, ptr(gsum), ptr(ws), ws.numel())
                     struct_stage_bwd(torch.ones(C, H, dtype=F32, device=g_direct.device), tp, ti, tx, w[0], w[1], w[2], w[3], w[4],
                                      lw, lb, gsum, None, g, need_input_grad=False, wpack=ctx.packs[0])
+                elif isinstance(ctx.states[k], tuple):
+                    g_direct, g_agg = struct_stage_bwd(ctx.states[k][1], p, plan.tagged_idx(rev, ctx.first[0]), xcls, w[0], w[1], w[2], w[3], w[4],
+                                                       lw, lb, g_direct, g_agg, g, need_input_grad=(k > 0), wpack=ctx.packs[int(rev)],
+                                                       heavy=plan.heavy(rev), table_own=ctx.first[0])
                 else:
                     g_direct, g_agg = struct_stage_bwd(ctx.states[k], p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb,
                                                        g_direct, g_agg, g, need_input_grad=(k > 0), wpack=ctx.packs[int(rev)],

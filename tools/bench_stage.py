@@ -62,7 +62,7 @@ def main():
 
         def fwd():
             _hip.call('mgv_struct_stage_fwd_x3', H, N, ptr(h), ptr(p), ptr(i), ptr(xcls), ptr(xtab), C, ptr(wpack), ptr(bc), ptr(bhh),
-                      ptr(lw), ptr(lb), 1e-5, ptr(out), 0, None, None)
+                      ptr(lw), ptr(lb), 1e-5, ptr(out), 0, None, None, None)
 
         res = {}
 
@@ -70,9 +70,9 @@ def main():
             common = (H, N, ptr(h), ptr(p), ptr(i), ptr(xcls), ptr(xtab), C, ptr(wpack), ptr(bc), ptr(bhh), ptr(lw), ptr(lb), 1e-5,
                       ptr(gy), ptr(ga_in), ptr(gd), ptr(ga), *[ptr(t) for t in acc])
             if which == 1:
-                _hip.call('mgv_struct_stage_bwd_x3', *common, 0, None, None)
+                _hip.call('mgv_struct_stage_bwd_x3', *common, 0, None, None, None)
             else:
-                _hip.call('mgv_struct_stage_bwd2_x3', *common, ptr(ws), ws.numel(), 0, None, None)
+                _hip.call('mgv_struct_stage_bwd2_x3', *common, ptr(ws), ws.numel(), 0, None, None, None)
 
         t_f = timed(fwd, iters)
         line = '%s fwd %.3f ms' % (tag, t_f)
