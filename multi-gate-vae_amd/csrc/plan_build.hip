@@ -171,18 +171,25 @@ __global__ __launch_bounds__(1024) void k_sort_heavy(const int32_t* heavy, const
     }
 }
 
-__global__ __launch_bounds__(256) void k_csr_finish_in(int64_t E, const int64_t* src, const int64_t* dst, const int32_t* eid_in, int32_t* in_src,
-                                                       int32_t* in_dst, int32_t* pos_in) {
+// Edges with a node id outside [0, N) are skipped by the count / fill kernels (status[0] = 1), so only the first in_ptr[N] (= out_ptr[N])
+// slots of eid_in / eid_out are filled: the finish kernels stop there and zero the tail of their outputs instead of following an
+// uninitialised edge id (the caller raises on the status; nothing launched before it reads the status may fault).
+__global__ __launch_bounds__(256) void k_csr_finish_in(int64_t E, int64_t N, const int32_t* in_ptr, const int64_t* src, const int64_t* dst,
+                                                       const int32_t* eid_in, int32_t* in_src, int32_t* in_dst, int32_t* pos_in) {
+    const int64_t valid = in_ptr[N];
     for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < E; s += (int64_t)gridDim.x * 256) {
+        if (s >= valid) { in_src[s] = 0; in_dst[s] = 0; continue; }
         const int e = eid_in[s];
         in_src[s] = (int32_t)src[e];
         in_dst[s] = (int32_t)dst[e];
         pos_in[e] = (int32_t)s;
     }
 }
-__global__ __launch_bounds__(256) void k_csr_finish_out(int64_t E, const int64_t* dst, const int32_t* eid_out, const int32_t* pos_in, int32_t* out_dst,
-                                                        int32_t* out_slot) {
+__global__ __launch_bounds__(256) void k_csr_finish_out(int64_t E, int64_t N, const int32_t* out_ptr, const int64_t* dst, const int32_t* eid_out,
+                                                        const int32_t* pos_in, int32_t* out_dst, int32_t* out_slot) {
+    const int64_t valid = out_ptr[N];
     for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < E; t += (int64_t)gridDim.x * 256) {
+        if (t >= valid) { out_dst[t] = 0; out_slot[t] = 0; continue; }
         const int e = eid_out[t];
         out_dst[t] = (int32_t)dst[e];
         out_slot[t] = pos_in[e];
@@ -368,6 +375,7 @@ extern "C" int mgv_plan_csr(int64_t N, int64_t E, const int64_t* src, const int6
     if (E == 0) return MGV_OK;
     hipMemcpyAsync(cur_in, in_ptr, N * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
     hipMemcpyAsync(cur_out, out_ptr, N * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+    hipMemsetAsync(eid_in, 0, 2 * E * sizeof(int32_t), st);      // eid_in, eid_out: slots no valid edge fills stay a valid edge id (the copies below)
     hipLaunchKernelGGL(k_csr_fill, dim3(blocks_for(E)), dim3(256), 0, st, E, N, src, dst, cur_in, cur_out, eid_in, eid_out);
     // per-node sorts; the heavy list reuses the cursor arrays (dead after the fill): list at cur_in[0..N), counter in status[1]
     for (int dir = 0; dir < 2; ++dir) {
@@ -381,8 +389,8 @@ extern "C" int mgv_plan_csr(int64_t N, int64_t E, const int64_t* src, const int6
     }
     if (in_eid) hipMemcpyAsync(in_eid, eid_in, E * sizeof(int32_t), hipMemcpyDeviceToDevice, st);        // original edge id of every CSR slot
     if (out_eid) hipMemcpyAsync(out_eid, eid_out, E * sizeof(int32_t), hipMemcpyDeviceToDevice, st);
-    hipLaunchKernelGGL(k_csr_finish_in, dim3(blocks_for(E)), dim3(256), 0, st, E, src, dst, eid_in, in_src, in_dst, pos_in);
-    hipLaunchKernelGGL(k_csr_finish_out, dim3(blocks_for(E)), dim3(256), 0, st, E, dst, eid_out, pos_in, out_dst, out_slot);
+    hipLaunchKernelGGL(k_csr_finish_in, dim3(blocks_for(E)), dim3(256), 0, st, E, N, in_ptr, src, dst, eid_in, in_src, in_dst, pos_in);
+    hipLaunchKernelGGL(k_csr_finish_out, dim3(blocks_for(E)), dim3(256), 0, st, E, N, out_ptr, dst, eid_out, pos_in, out_dst, out_slot);
     MGV_LAUNCH_RET();
 }
 

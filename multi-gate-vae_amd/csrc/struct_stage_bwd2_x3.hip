@@ -20,8 +20,15 @@
 #ifndef MGV_BWD2_D
 #define MGV_BWD2_D 2
 #endif
+#ifndef MGV_ABL
+#define MGV_ABL 0            // timing ablations of diagnostic builds (results are wrong): 1 no MFMA, 2 light VALU in P2/P3, 4 no row gathers
+#endif
 
 namespace mgv {
+
+#if MGV_ABL & 1
+#define mma_x3(c, ah, al, bh, bl) asm volatile("" :: "v"(ah), "v"(al), "v"(bh), "v"(bl))
+#endif
 
 struct B2 {
     static constexpr int H = 64;
@@ -154,7 +161,11 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             float4 acc[2], own[2], dy[2];
             float deg[2];
             int cls[2];
+#if MGV_ABL & 4
+            for (int rr = 0; rr < 2; ++rr) { acc[rr] = make_float4(0.1f * lr, 0.2f, 0.3f, 0.4f); own[rr] = acc[rr]; dy[rr] = acc[rr]; deg[rr] = 2.f; cls[rr] = 1; }
+#else
             tile_rows<H, 2, true, MGV_BWD2_D>(a, base, grp, 32, lr, idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).idx, *idx_lds(idx_base, b).dmax(), acc, own, dy, deg, cls);
+#endif
             // (0) the previous tile's P4 (last reader of the planes and of xe) is over in every wave; placed here, behind the
             //     gather, it waits where the waves wait for memory anyway
             __syncthreads();
@@ -259,6 +270,10 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             const f32x4 rx0 = s_ex[(w * 6 + il * 3 + 0) * 64 + lane], rx1 = s_ex[(w * 6 + il * 3 + 1) * 64 + lane], rx2 = s_ex[(w * 6 + il * 3 + 2) * 64 + lane];
             const f32x4 sr = rx0 + oa[0][il], sz = rx1 + oa[1][il];
             const f32x4 pn = m ? rx2 : oa[2][il], hn = m ? oa[2][il] : rx2;
+#if MGV_ABL & 2
+            vr[il] = rx0 + oa[0][il]; vz[il] = rx1 + oa[1][il]; vn[il] = rx2 + oa[2][il]; vg[il] = vr[il]; vd[il] = vz[il]; mw[il] = (float)row;
+            continue;
+#endif
             const float deg = sv.deg[row];
             const float* xt = sv.xtab + sv.cls[row] * 3 * H + c0;
             const bf16x4 hh = *reinterpret_cast<const bf16x4*>(hin_hi + row * LDP + c0);
@@ -298,6 +313,19 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
         for (int il = 0; il < 2; ++il) {
             LANE_IDS
             const int row = 16 * (2 * m + il) + r;
+#if MGV_ABL & 2
+            {
+                __bf16* dst = s_dg + row * LDP + c0;
+                const bf16x4 h0 = bf16x4{(__bf16)vr[il][0], (__bf16)vr[il][1], (__bf16)vr[il][2], (__bf16)vr[il][3]};
+                const bf16x4 h1 = bf16x4{(__bf16)vz[il][0], (__bf16)vz[il][1], (__bf16)vz[il][2], (__bf16)vz[il][3]};
+                const bf16x4 h2 = bf16x4{(__bf16)vn[il][0], (__bf16)vn[il][1], (__bf16)vn[il][2], (__bf16)vn[il][3]};
+                st_bf4(dst, h0); st_bf4(dst + PE, h1); st_bf4(dst + 2 * PE, h2); st_bf4(dst + 3 * PE, h0);
+                st_bf4(dst + 4 * PE, h1); st_bf4(dst + 5 * PE, h2); st_bf4(dst + 6 * PE, h0); st_bf4(dst + 7 * PE, h1);
+                dhz[il] = vd[il] + mw[il];
+                if (m == 0) s_dhz[(wc * 2 + il) * 64 + lane] = dhz[il];
+                continue;
+            }
+#endif
             const float4 dy = ld4(s_dy + row * LDF + c0);
             const float dy_[4] = {dy.x, dy.y, dy.z, dy.w};
             const bf16x4 hh = *reinterpret_cast<const bf16x4*>(hin_hi + row * LDP + c0);

@@ -158,11 +158,12 @@ class FunctionalModel(nn.Module):
                 else negative_sampling(pos_edge_index, hs.shape[0], keys=edge_keys)
         if plan is not None and hs.is_cuda and torch.is_tensor(neg_edge_index) and neg_edge_index.shape[1] > 0:
             # given negatives: bucket them once (cached on the tensor's identity) so that their gradient needs no atomics either
-            cache = getattr(self, '_neg_cache', None)
+            # kept on the batch's plan (like its pair lists), not on the model: several batches with fixed negatives each keep theirs
+            cache = getattr(plan, '_neg_cache', None)
             key = (neg_edge_index.data_ptr(), neg_edge_index._version, tuple(neg_edge_index.shape), hs.shape[0])
             if cache is None or cache[0] is not neg_edge_index or cache[1] != key:      # same tensor object, not written since
                 from .sampling import bucket_negatives
-                cache = self._neg_cache = (neg_edge_index, key, bucket_negatives(neg_edge_index.long(), hs.shape[0]))
+                cache = plan._neg_cache = (neg_edge_index, key, bucket_negatives(neg_edge_index.long(), hs.shape[0]))
             neg_edge_index = cache[2]
         if isinstance(neg_edge_index, NegativeEdges):
             neg_csr, neg_edge_index = neg_edge_index.csr, neg_edge_index.edge_index

@@ -70,8 +70,12 @@ class GraphPlan:
         status = torch.empty(2, **i32)
         _hip.call('mgv_plan_csr', N, E, ptr(src), ptr(dst), ptr(self.in_ptr), ptr(self.in_src), ptr(self.in_dst), ptr(self.out_ptr),
                   ptr(self.out_dst), ptr(self.out_slot), None, None, ptr(scratch), n_s, ptr(status))
-        self._status = status            # read together with the level checks (one host round trip per batch)
+        # Read lazily (with the level checks: one host round trip per batch).  The arrays are safe to launch on before that: the
+        # CSR kernels skip out-of-range edges and zero the unfilled tail, so every stored id lies in [0, N).
+        self._status = status
         self._keep = (src, dst)
+        if N == 0 and E > 0:
+            raise ValueError('edge_index holds node ids outside [0, num_nodes)')
 
     def asap_levels(self):
         """ASAP level of every node (the round of utils/dag_utils.top_sort in which it is evaluated = longest path from a source),
@@ -122,11 +126,11 @@ class GraphPlan:
         """The neighbour array of `csr(reverse)` with each neighbour's (degree, class) table row in the top byte (entry = node | row << 24):
         what the struct-stage kernels read in table mode.  Cached per direction and class-id tensor."""
         cache = self.__dict__.setdefault('_tagged', {})
-        key = (reverse, class_id.data_ptr())
-        if key not in cache:
+        hit = cache.get(reverse)
+        if hit is None or hit[0] is not class_id:            # the entry holds the tensor itself: an address can be reused, an object cannot
             idx = self.csr(reverse)[1]
-            cache[key] = (idx | (class_id[idx.long()] << 24)).to(torch.int32).contiguous()
-        return cache[key]
+            hit = cache[reverse] = (class_id, (idx | (class_id[idx.long()] << 24)).to(torch.int32).contiguous())
+        return hit[1]
 
     HEAVY_ROW = 64      # csrc/struct_stage_x3_common.h: kHeavyRow
 
@@ -240,9 +244,18 @@ class GraphPlan:
         idx = torch.zeros(max(int(p[-1].item()), 1), **i32)
         return (cid, C, p.to(torch.int32).contiguous(), idx, cls_x[:C].contiguous())
 
+    def _drop_level_caches(self):
+        """Caches derived from gslot / level (and the tagged neighbour arrays): stale once the levels are set again, which
+        `data.plan_of` does when a batch meets a model with another gate set."""
+        self._groups = None
+        self.__dict__.pop('_heavy_seg', None)
+        self.__dict__.pop('_tagged', None)
+
     def _set_levels_hip(self, gate, forward_level, gate_ids):
         from . import _hip
         from ._hip import ptr
+        self._check_status()                 # before anything consumes the CSR
+        self._drop_level_caches()
         N, E, dev, T = self.N, self.E, self.device, len(gate_ids)
         i32 = dict(dtype=torch.int32, device=dev)
         g = gate.reshape(-1).to(dev, torch.float32).contiguous()
@@ -258,7 +271,6 @@ class GraphPlan:
         flags = torch.zeros(2, **i32)                       # [max level, level-order violation]
         _hip.call('mgv_plan_keys', N, T, ptr(g), ptr(lv), tab, ptr(self.gslot), ptr(self.level), ptr(key), ptr(flags))
         _hip.call('mgv_plan_check_levels', E, ptr(self.in_src), ptr(self.in_dst), ptr(self.gslot), ptr(self.level), ptr(flags[1:]))
-        self._check_status()
         maxlevel, bad = (int(v) for v in flags.tolist())    # the batch's first host round trip
         if bad:
             raise ValueError('forward_level is not a topological levelisation of edge_index')
@@ -302,6 +314,7 @@ class GraphPlan:
             done = self._set_levels_hip(gate, forward_level, gate_ids)
             if done is not False:
                 return self
+        self._drop_level_caches()
         dev = self.device
         g = gate.reshape(-1).to(dev).long()
         lv = forward_level.reshape(-1).to(dev).long()

@@ -683,6 +683,8 @@ def pair_lists(tt_pair_index, num_nodes):
     status = torch.empty(2, **i32)
     _hip.call('mgv_plan_csr', N, P, ptr(pa), ptr(pb), ptr(b_ptr), ptr(junk[0]), ptr(junk[1]), ptr(a_ptr), ptr(junk[2]), ptr(junk[3]),
               ptr(b_pair), ptr(a_pair), ptr(scratch), n_s, ptr(status))
+    if int(status[0].item()) != 0:           # built once per batch and cached: one host read
+        raise ValueError('tt_pair_index holds node ids outside [0, num_nodes)')
     return a_ptr, a_pair, b_ptr, b_pair
 
 

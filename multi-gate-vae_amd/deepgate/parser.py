@@ -116,13 +116,22 @@ class NpzParser:
                 dist = None
         except ImportError:
             dist = None
+        # With an initialised process group (call init_process_group BEFORE constructing the parser) rank 0 parses and publishes the
+        # cache while the others wait; rank 0 always reaches the barrier (try/finally), so a parse error on it does not leave the
+        # others waiting for the group timeout — they then fail on the missing cache.  Without a group every rank parses for
+        # itself; the atomic publish below keeps that safe.
         if dist is not None and rank != 0:
-            dist.barrier()                      # rank 0 parses and publishes the cache, the others read it
-        if os.path.exists(cache):
-            graphs = list(np.load(cache, allow_pickle=True)['graphs'])
+            dist.barrier()
+        try:
+            return NpzParser._load_or_parse(cache, circuit_path, label_path, circuit_type)
+        finally:
             if dist is not None and rank == 0:
                 dist.barrier()
-            return graphs
+
+    @staticmethod
+    def _load_or_parse(cache, circuit_path, label_path, circuit_type):
+        if os.path.exists(cache):
+            return list(np.load(cache, allow_pickle=True)['graphs'])
         circuits = np.load(circuit_path, allow_pickle=True)['circuits'].item()
         labels = None if circuit_type == 'aig' else np.load(label_path, allow_pickle=True)['labels'].item()
         tt_key = 'tt_sim' if circuit_type == 'aig' else 'tt_dis'
@@ -143,6 +152,4 @@ class NpzParser:
         np.savez(tmp, graphs=arr)
         os.replace(tmp, cache)
         print('[INFO] Inmemory dataset save: ', cache)
-        if dist is not None and rank == 0:
-            dist.barrier()
         return graphs

@@ -43,6 +43,8 @@ def bucket_negatives(neg, N):
     status = torch.empty(2, **i32)
     _hip.call('mgv_plan_csr', N, E, ptr(src), ptr(dst), ptr(in_ptr), ptr(in_src), ptr(in_dst), ptr(out_ptr), ptr(out_dst), ptr(out_slot),
               None, None, ptr(scratch), n_s, ptr(status))
+    if int(status[0].item()) != 0:           # caller-supplied pairs, bucketed once and cached: one host read
+        raise ValueError('neg_edge_index holds node ids outside [0, num_nodes)')
     counts = (out_ptr[1:] - out_ptr[:-1]).long()
     srt_src = torch.repeat_interleave(torch.arange(N, device=dev), counts, output_size=E)
     srt = torch.stack([srt_src, out_dst[:E].long()])

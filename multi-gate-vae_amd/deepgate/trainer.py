@@ -184,6 +184,7 @@ class Trainer():
         if side is not None:
             hs, hf = self.model(batch, after_hs=recon_on_side)
             loss, pred_bin, gt_bin = self.model.after_hs_out
+            self.model.after_hs_out = None          # the model must not keep this step's loss graph alive
             main = torch.cuda.current_stream()
             main.wait_stream(side)
             for t in (loss, pred_bin, gt_bin, self.model.last_confusion):

@@ -80,8 +80,25 @@ def test_out_of_range_node_ids_are_reported(monkeypatch):
     from deepgate.graph_plan import GraphPlan
     monkeypatch.setenv('MGV_PLAN', 'hip')
     p = GraphPlan(torch.tensor([[0, 1, 9], [1, 2, 0]], device=dev), 3)
+    # the CSR kernels skip the bad edge: two valid slots, the unfilled tail zeroed, every stored id inside [0, N)
+    assert p.in_ptr.tolist() == [0, 0, 1, 2] and p.out_ptr.tolist() == [0, 1, 2, 2]
+    for arr in (p.in_src, p.in_dst, p.out_dst, p.out_slot):
+        assert int(arr.min()) >= 0 and int(arr.max()) < 3 and int(arr[2]) == 0
     with pytest.raises(ValueError):
         p._check_status()
+    # the status is read BEFORE anything consumes the CSR
+    p2 = GraphPlan(torch.tensor([[0, 1, -4], [1, 2, 0]], device=dev), 3)
+    with pytest.raises(ValueError, match='outside'):
+        p2.set_levels(torch.tensor([0., 1., 1.], device=dev), torch.tensor([0, 1, 2], device=dev), [1, 2])
+
+
+def test_out_of_range_pairs_and_negatives_raise():
+    dev = _dev()
+    from deepgate import ops, sampling
+    with pytest.raises(ValueError, match='tt_pair_index'):
+        ops.pair_lists(torch.tensor([[0, 1, 7], [1, 2, 0]], device=dev), 3)
+    with pytest.raises(ValueError, match='neg_edge_index'):
+        sampling.bucket_negatives(torch.tensor([[0, 1, 2], [1, 5, 0]], device=dev), 3)
 
 
 @pytest.mark.parametrize('ctype', ['aig', 'mig', 'xag', 'xmg'])

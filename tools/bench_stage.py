@@ -76,7 +76,8 @@ def main():
 
         t_f = timed(fwd, iters)
         line = '%s fwd %.3f ms' % (tag, t_f)
-        for which in (1, 2):
+        only2 = os.environ.get('STAGE_ONLY2') == '1'      # ablation builds: time the second backward only, no comparison
+        for which in ((2,) if only2 else (1, 2)):
             acc, gd, ga = grads(), torch.empty_like(h), torch.empty_like(h)
             bwd(which, acc, gd, ga)
             torch.cuda.synchronize()
@@ -84,6 +85,8 @@ def main():
             t_b = timed(lambda: bwd(which, grads(), gd, ga), iters)
             line += ' | bwd%d %.3f ms' % (which, t_b)
         print(line)
+        if only2:
+            continue
         names = ['dWc', 'dbc', 'dWhh', 'dbhh', 'dxtab', 'dlnw', 'dlnb', 'g_direct', 'g_agg']
         worst = 0.0
         for n, a1, a2 in zip(names, res[1], res[2]):

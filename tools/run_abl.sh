@@ -1,0 +1,7 @@
+#!/bin/bash
+# times the struct-stage backward of every ablation build under tools/bin (diagnostic; results of those builds are wrong by design)
+export STAGE_ONLY2=1
+for v in "$@"; do
+  echo "== ablation $v"
+  MGV_LIB=$PWD/tools/bin/libabl$v.so python tools/bench_stage.py 64 5 || exit 1
+done
