@@ -21,14 +21,17 @@
 #define MGV_BWD2_D 2
 #endif
 #ifndef MGV_ABL
-#define MGV_ABL 0            // timing ablations of diagnostic builds (results are wrong): 1 no MFMA, 2 light VALU in P2/P3, 4 no row gathers
+#define MGV_ABL 0            // timing ablations of diagnostic builds (results are wrong): 1 no MFMA, 2 light VALU in P2/P3, 4 no row gathers, 8 no output stores, 16 dgrad weights loaded once, 32 (with 1) no LDS fragment reads
 #endif
 
 namespace mgv {
 
-#if MGV_ABL & 1
+#if (MGV_ABL & 33) == 33
+#define mma_x3(c, ah, al, bh, bl) ((void)0)                  // and no LDS fragment reads either
+#elif MGV_ABL & 1
 #define mma_x3(c, ah, al, bh, bl) asm volatile("" :: "v"(ah), "v"(al), "v"(bh), "v"(bl))
 #endif
+
 
 struct B2 {
     static constexpr int H = 64;
@@ -405,7 +408,9 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             const int it0 = 2 * (wc >> 1), jt0 = 2 * (wc & 1), ig = wc & 1;
             bf16x8 wd_hi[3], wd_lo[3];
             int oz = 0;
+#if !(MGV_ABL & 16)
             asm volatile("" : "+s"(oz));                    // opaque per tile: keeps the (loop-invariant) loads inside the loop
+#endif
             const __bf16* wd_p = a.wpack + wd_off + oz;
             if (need_dgrad) {
 #pragma unroll
@@ -469,7 +474,11 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                         mma_x3(dgo[i], wd_hi[k], wd_lo[k], ldfrag(ph + off), ldfrag(ph + PE + off));
                     }
                     const int64_t node = base + i * 16 + r;
+#if MGV_ABL & 8
+                    if (node < a.N && dgo[i][0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(go + node * H + c0) = dgo[i];
+#else
                     if (node < a.N) *reinterpret_cast<f32x4*>(go + node * H + c0) = dgo[i];
+#endif
                 }
             }
         }
@@ -555,6 +564,14 @@ __global__ __launch_bounds__(256) void k_struct_stage_bwd2_reduce(B2RedArgs a) {
     }
 }
 
+// fixed-order sum of `grid` workgroup slabs into the gradient accumulators (shared with struct_stage_bwd3_x3.hip: same slab layout)
+int launch_stage_slab_reduce(const StageX3Args& s, float* workspace, int grid, hipStream_t st) {
+    B2RedArgs ra{workspace, grid, s.C, s.dWc, s.dbc, s.dWhh, s.dbhh, s.dxtab, s.dlnw, s.dlnb};
+    constexpr int NT = B2::SLAB_W / 4 + 2 * B2::H / 4;
+    hipLaunchKernelGGL(k_struct_stage_bwd2_reduce, dim3((NT + 63) / 64), dim3(256), 0, st, ra);
+    MGV_LAUNCH_RET();
+}
+
 int launch_bwd2_x3(const StageX3Args& s, float* workspace, int64_t workspace_floats, hipStream_t st) {
     static bool set[64] = {false};      // per device: each device loads its own copy of the code object
     int dev = 0;
@@ -565,10 +582,7 @@ int launch_bwd2_x3(const StageX3Args& s, float* workspace, int64_t workspace_flo
     if (workspace == nullptr || workspace_floats < (int64_t)grid * B2::SLAB) return MGV_EINVAL;
     B2Args a{s, workspace};
     hipLaunchKernelGGL(k_struct_stage_bwd2_x3, dim3(grid), dim3(kThreadsX3), B2::bytes, st, a);
-    B2RedArgs ra{workspace, grid, s.C, s.dWc, s.dbc, s.dWhh, s.dbhh, s.dxtab, s.dlnw, s.dlnb};
-    constexpr int NT = B2::SLAB_W / 4 + 2 * B2::H / 4;
-    hipLaunchKernelGGL(k_struct_stage_bwd2_reduce, dim3((NT + 63) / 64), dim3(256), 0, st, ra);
-    MGV_LAUNCH_RET();
+    return launch_stage_slab_reduce(s, workspace, grid, st);
 }
 
 }  // namespace mgv

@@ -72,7 +72,7 @@ def main():
             if which == 1:
                 _hip.call('mgv_struct_stage_bwd_x3', *common, 0, None, None, None)
             else:
-                _hip.call('mgv_struct_stage_bwd2_x3', *common, ptr(ws), ws.numel(), 0, None, None, None)
+                _hip.call('mgv_struct_stage_bwd%d_x3' % which, *common, ptr(ws), ws.numel(), 0, None, None, None)
 
         t_f = timed(fwd, iters)
         line = '%s fwd %.3f ms' % (tag, t_f)
@@ -89,19 +89,21 @@ def main():
             continue
         names = ['dWc', 'dbc', 'dWhh', 'dbhh', 'dxtab', 'dlnw', 'dlnb', 'g_direct', 'g_agg']
         worst = 0.0
-        for n, a1, a2 in zip(names, res[1], res[2]):
-            scale = float(a1.abs().max()) + 1e-30
-            err = float((a1 - a2).abs().max()) / scale
-            worst = max(worst, err)
-            if err > 1e-4:
-                print('   %-9s deviates: %.3g of its scale (%.3g)' % (n, err, scale))
-        print('   largest bwd1-vs-bwd2 deviation: %.3g of the tensor scale' % worst)
-        # run-to-run determinism of bwd2
-        acc2, gd2, ga2 = grads(), torch.empty_like(h), torch.empty_like(h)
-        bwd(2, acc2, gd2, ga2)
-        torch.cuda.synchronize()
-        same = all(torch.equal(x, y) for x, y in zip(acc2 + [gd2, ga2], res[2]))
-        print('   bwd2 bit-identical on a second run: %s' % same)
+        for other in (2,):
+            worst = 0.0
+            for n, a1, a2 in zip(names, res[1], res[other]):
+                scale = float(a1.abs().max()) + 1e-30
+                err = float((a1 - a2).abs().max()) / scale
+                worst = max(worst, err)
+                if err > 1e-4:
+                    print('   %-9s deviates: %.3g of its scale (%.3g)' % (n, err, scale))
+            print('   largest bwd1-vs-bwd%d deviation: %.3g of the tensor scale' % (other, worst))
+            # run-to-run determinism
+            acc2, gd2, ga2 = grads(), torch.empty_like(h), torch.empty_like(h)
+            bwd(other, acc2, gd2, ga2)
+            torch.cuda.synchronize()
+            same = all(torch.equal(x, y) for x, y in zip(acc2 + [gd2, ga2], res[other]))
+            print('   bwd%d bit-identical on a second run: %s' % (other, same))
 
 
 if __name__ == '__main__':
