@@ -30,6 +30,8 @@ def get_parse_args(argv=None):
     parser.add_argument('--synthetic_levels', type=int, default=30, help='logic levels per synthetic graph')
     parser.add_argument('--data_dir', type=str, default='', help='directory with graphs.npz (and labels.npz for mig/xag/xmg): '
                         'the reference hard-codes it in train.py')
+    parser.add_argument('--device_levels', action='store_true', help='skip the host levelisation of the dataset: every batch is levelised '
+                        'on the device when its plan is built (csrc/plan_build.hip)')
     parser.add_argument('--circuit_file', type=str, default='graphs.npz')
     parser.add_argument('--label_file', type=str, default='labels.npz')
     parser.add_argument('--stage_epochs', type=int, nargs=3, default=[100, 60, 60],

@@ -1,0 +1,170 @@
+"""Batch prefetcher: what stands between the dataset and `Trainer.train_step` (trainer.py:189-195,223 of the reference: a
+DataLoader whose workers collate, then `batch.to(device)` inside the loop).
+
+Per batch, on a host worker thread: the graphs of the batch are collated straight into pinned staging buffers (one pass per
+field, index fields offset on the way: `OrderedData.__inc__/__cat_dim__`, parser_func.py:28-40), copied to the device on that
+worker's own HIP stream, and the batch's graph plan (CSRs, level tiles: csrc/plan_build.hip) is built on the same stream.  The
+consumer receives the batch together with an event; its stream waits for the event, the host never does.  `depth` batches are
+in flight, so collate + H2D + plan build of batch k+1.. run beside the train step of batch k.
+On a CPU device the same code path runs without streams (host-logic tests).
+"""
+import collections
+import concurrent.futures
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from .data import CircuitBatch, plan_of
+
+_CAT1 = ('edge_index', 'tt_pair_index', 'neg_edge_index')        # concatenated along dim 1, the others along dim 0
+_KEYS = ('x', 'edge_index', 'gate', 'forward_level', 'forward_index', 'prob', 'tt_pair_index', 'tt_sim', 'neg_edge_index')
+
+
+class _Staging:
+    """Pinned host buffers of one in-flight batch, grown on demand and reused once the batch's copy has completed."""
+
+    def __init__(self, pin):
+        self.pin, self.buf, self.event = pin, {}, None
+
+    def view(self, key, shape, dtype):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        b = self.buf.get(key)
+        if b is None or b.numel() < n:
+            b = self.buf[key] = torch.empty(max(n, 1), dtype=torch.uint8, pin_memory=self.pin)
+        t = b[:n].view(getattr(torch, np.dtype(dtype).name)).reshape(shape)
+        return t
+
+
+def collate_into(graphs, staging, keys=None):
+    """Collate per-graph array dicts into tensors backed by `staging`'s buffers (same result as synthetic.collate)."""
+    keys = [k for k in (keys or _KEYS) if all(k in g for g in graphs)]
+    out, off, graph_ptr = {}, 0, [0]
+    views = {}
+    for k in keys:
+        a0 = np.asarray(graphs[0][k])
+        if k in _CAT1:
+            shape = (a0.shape[0], sum(np.asarray(g[k]).shape[1] for g in graphs))
+        else:
+            shape = (sum(np.asarray(g[k]).shape[0] for g in graphs),) + a0.shape[1:]
+        t = staging.view(k, shape, a0.dtype)
+        views[k] = (t, t.numpy(), 0)
+        out[k] = t
+    for g in graphs:
+        for k in keys:
+            t, v, pos = views[k]
+            a = np.asarray(g[k])
+            n = a.shape[1] if k in _CAT1 else a.shape[0]
+            dst = v[:, pos:pos + n] if k in _CAT1 else v[pos:pos + n]
+            if 'index' in k:
+                np.add(a, off, out=dst)
+            else:
+                np.copyto(dst, a)
+            views[k] = (t, v, pos + n)
+        off += int(g['num_nodes'])
+        graph_ptr.append(off)
+    out['graph_ptr'] = torch.tensor(graph_ptr, dtype=torch.int64)
+    return out, off
+
+
+class BatchPrefetcher:
+    """Iterate device-resident `CircuitBatch` objects over `chunks` (an iterable of lists of per-graph array dicts).
+
+    gate_ids : build the GraphPlan for this aggregator set on the worker's stream (None: the model builds it on first use)
+    workers  : host threads that collate / copy / plan (numpy releases the GIL in the large copies)
+    depth    : batches in flight (>= workers)
+    skip     : fields left out (e.g. 'neg_edge_index' when negatives are drawn on the device)
+    """
+
+    def __init__(self, chunks, device, gate_ids=None, workers=2, depth=None, skip=()):
+        self.chunks = iter(chunks)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == 'cuda'
+        self.gate_ids = list(gate_ids) if gate_ids is not None else None
+        self.workers = max(int(workers), 1)
+        self.depth = max(int(depth) if depth is not None else self.workers + 1, self.workers)
+        self.keys = [k for k in _KEYS if k not in skip]
+        self._free = queue.Queue()
+        for _ in range(self.depth + 1):
+            self._free.put(_Staging(self.cuda))
+        self._tls = threading.local()
+        self._pool = concurrent.futures.ThreadPoolExecutor(self.workers, thread_name_prefix='mgv-prefetch')
+
+    # ---- worker side
+    def _stream(self):
+        s = getattr(self._tls, 'stream', None)
+        if s is None and self.cuda:
+            torch.cuda.set_device(self.device)
+            s = self._tls.stream = torch.cuda.Stream(self.device)
+        return s
+
+    def _take_staging(self):
+        st = self._free.get()
+        if st.event is not None:             # its previous batch's host-to-device copy (long finished by the time the slot comes round)
+            st.event.synchronize()
+            st.event = None
+        return st
+
+    def _produce(self, graphs):
+        st = self._take_staging()
+        host, _ = collate_into(graphs, st, self.keys)
+        b = CircuitBatch()
+        if not self.cuda:
+            for k, t in host.items():
+                setattr(b, k, t.clone() if k != 'graph_ptr' else t)
+            b.num_graphs = len(graphs)
+            self._free.put(st)
+            if self.gate_ids is not None:
+                plan_of(b, self.gate_ids)
+            return b, None
+        stream = self._stream()
+        with torch.cuda.stream(stream):
+            for k, t in host.items():
+                setattr(b, k, t if k == 'graph_ptr' else t.to(self.device, non_blocking=True))
+            b.num_graphs = len(graphs)
+            copied = torch.cuda.Event()
+            copied.record(stream)
+            st.event = copied
+            self._free.put(st)
+            if self.gate_ids is not None:
+                plan_of(b, self.gate_ids)        # its few host read-backs wait on THIS stream only
+            ready = torch.cuda.Event()
+            ready.record(stream)
+        return b, ready
+
+    # ---- consumer side
+    def __iter__(self):
+        pending = collections.deque()
+        try:
+            while True:
+                while len(pending) < self.depth:
+                    try:
+                        graphs = next(self.chunks)
+                    except StopIteration:
+                        break
+                    pending.append(self._pool.submit(self._produce, graphs))
+                if not pending:
+                    return
+                b, ready = pending.popleft().result()
+                if ready is not None:
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_event(ready)
+                    # the tensors were allocated on the worker's stream: tell the allocator that this stream uses them too
+                    for obj in (b, getattr(b, '_mgv_plan', None)):
+                        if obj is None:
+                            continue
+                        for v in obj.__dict__.values():
+                            if torch.is_tensor(v) and v.is_cuda:
+                                v.record_stream(cur)
+                            elif isinstance(v, (tuple, list)):
+                                for u in v:
+                                    if torch.is_tensor(u) and u.is_cuda:
+                                        u.record_stream(cur)
+                yield b
+        finally:
+            for f in pending:
+                f.cancel()
+
+    def close(self):
+        self._pool.shutdown(wait=True, cancel_futures=True)

@@ -145,10 +145,13 @@ CONFIGS = {
 }
 
 
-def make_batch(config, batch=None, first_graph=0):
-    """Synthetic batch for BASELINE config `config` (1..5); graph g uses seed 1000*config + g."""
+def make_graphs(config, batch=None, first_graph=0):
+    """The graphs of a synthetic batch for BASELINE config `config` (1..5) as per-graph array dicts; graph g uses seed 1000*config + g."""
     c = dict(CONFIGS[config])
     b = batch if batch is not None else c['batch']
-    gs = [make_graph(c['ctype'], c['n_nodes'], c['n_levels'], 1000 * config + first_graph + i,
-                     n_inputs=c['n_inputs']) for i in range(b)]
-    return collate(gs)
+    return [make_graph(c['ctype'], c['n_nodes'], c['n_levels'], 1000 * config + first_graph + i, n_inputs=c['n_inputs']) for i in range(b)]
+
+
+def make_batch(config, batch=None, first_graph=0):
+    """Synthetic batch for BASELINE config `config` (1..5), collated."""
+    return collate(make_graphs(config, batch, first_graph))

@@ -17,6 +17,7 @@ from torch import nn
 from . import ops
 from .data import CircuitBatch
 from .optim import FlatAdam
+from .prefetch import BatchPrefetcher
 from .sampling import sorted_edge_keys
 from .synthetic import collate as collate_arrays
 from .utils.logger import Logger
@@ -48,11 +49,15 @@ class GraphLoader:
     def __len__(self):
         return len(self._indices()) // self.batch_size
 
-    def __iter__(self):
+    def chunks(self):
+        """The epoch's batches as lists of per-graph array dicts (what a BatchPrefetcher collates on its worker threads)."""
         idx = self._indices()
         self.epoch += 1
         for b in range(len(idx) // self.batch_size):
-            chunk = [self.graphs[i] for i in idx[b * self.batch_size:(b + 1) * self.batch_size]]
+            yield [self.graphs[i] for i in idx[b * self.batch_size:(b + 1) * self.batch_size]]
+
+    def __iter__(self):
+        for chunk in self.chunks():
             yield CircuitBatch.from_arrays(collate_arrays(chunk))
 
 
@@ -286,8 +291,11 @@ class Trainer():
             for phase in ['train', 'val']:
                 loader = train_loader if phase == 'train' else val_loader
                 self.model.train() if phase == 'train' else self.model.eval()
-                for iter_id, batch in enumerate(loader):
-                    batch = batch.to(self.device)
+                # collate, host-to-device copy and plan build of the next batches run on worker threads / their own HIP streams
+                # beside the current step (deepgate/prefetch.py); the reference does `batch.to(device)` inside the loop (trainer.py:223)
+                batches = BatchPrefetcher(loader.chunks(), self.device, gate_ids=[g for _, g in getattr(self.model, 'GATES', [])] or None,
+                                          workers=max(self.num_workers, 2))
+                for iter_id, batch in enumerate(batches):
                     time_stamp = time.time()
                     if phase == 'train':
                         loss_status = self.train_step(batch)
@@ -299,6 +307,7 @@ class Trainer():
                     account(self.enqueue_metrics(loss_status))
                     batch_time.update(time.time() - time_stamp)
                 account(self.flush_metrics())
+                batches.close()
                 if phase == 'train' and self.model_epoch % 10 == 0 and self.rank == 0:
                     self.save(os.path.join(self.log_dir, 'model_{:}.pth'.format(self.model_epoch)))
                     self.save(os.path.join(self.log_dir, 'model_last.pth'))

@@ -34,7 +34,7 @@ def main(argv=None):
         train_dataset, val_dataset = graphs[:cut], graphs[cut:]
     elif args.data_dir:
         dataset = deepgate.NpzParser(args.data_dir, os.path.join(args.data_dir, args.circuit_file),
-                                     os.path.join(args.data_dir, args.label_file), args.type)
+                                     os.path.join(args.data_dir, args.label_file), args.type, levelise=not args.device_levels)
         train_dataset, val_dataset = dataset.get_dataset()
     else:
         raise SystemExit('pass --data_dir DIR (graphs.npz [+ labels.npz]) or --synthetic N')

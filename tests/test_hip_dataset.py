@@ -1,0 +1,123 @@
+"""GPU test of SURVEY.md §8(f2) end to end: a MixGate-layout dataset (graphs.npz [+ labels.npz]: the reference's own fixture
+circuits with shuffled node ids, tests/golden/g6_loader.npz, plus random DAGs) goes through `train.py --data_dir` —
+NpzParser -> GraphLoader -> prefetcher (collate, H2D, device levelisation + plan build) -> train steps — and the first batch's
+three losses equal the oracle's on the same parsed batch (train.py:25-41, deepgate/parser.py:71-125, trainer.py:189-195,223)."""
+import importlib
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, PKG_PARENT
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_dag(rng, n, n_in, ctype):
+    src, dst = [], []
+    gate = np.zeros(n, dtype=np.int64)
+    for v in range(n_in, n):
+        k = int(rng.integers(1, 3 if ctype == 'aig' else 4))
+        ps = rng.choice(v, size=min(k, v), replace=False)
+        if ctype == 'aig':
+            gate[v] = {1: 2, 2: 1}[len(ps)]                               # NOT 2, AND 1
+        else:
+            gate[v] = {1: 2, 2: int(rng.choice([3, 4, 5])), 3: 1}[len(ps)]    # NOT 2, AND/OR/XOR 3/4/5, MAJ 1
+        src += list(ps)
+        dst += [v] * len(ps)
+    return np.array([src, dst], dtype=np.int64), gate
+
+
+def _write_dataset(root, ctype):
+    """graphs.npz (+ labels.npz) in the MixGate layout: the fixture circuit (ids shuffled by the fixture's generator) and 9 random
+    DAGs whose ids are shuffled here, so that levels are not monotone in the node id."""
+    z = np.load(os.path.join(GOLDEN, 'g6_loader.npz'))
+    rng = np.random.default_rng(5)
+    circuits, labels = {}, {}
+
+    def put(name, x, ei, prob, tt, pairs):
+        lab = {'prob': prob, 'tt_pair_index': pairs, ('tt_sim' if ctype == 'aig' else 'tt_dis'): tt}
+        if ctype == 'aig':
+            circuits[name] = dict(x=x, edge_index=ei, gate=x[:, 1:2].copy(), **lab)
+        else:
+            circuits[name] = dict(x=x, edge_index=ei)
+            labels[name] = lab
+    put('fixture', z[ctype + '_in_x'], z[ctype + '_in_edge_index'], z[ctype + '_in_prob'], z[ctype + '_in_tt_sim'], z[ctype + '_in_tt_pair_index'])
+    for i in range(9):
+        n = 90 + 17 * i
+        ei, gate = _random_dag(rng, n, 8, ctype)
+        perm = rng.permutation(n)
+        x = np.zeros((n, 3)); x[perm, 0] = np.arange(n); x[perm, 1] = gate
+        ei = perm[ei]
+        pairs = rng.integers(0, n, size=(2, 24))
+        put('rand%d' % i, x, ei if ctype == 'aig' else ei.T, rng.random(n), rng.random(24), pairs if ctype == 'aig' else pairs.T)
+    os.makedirs(root, exist_ok=True)
+    np.savez(os.path.join(root, 'graphs.npz'), circuits=np.array(circuits, dtype=object))
+    np.savez(os.path.join(root, 'labels.npz'), labels=np.array(labels, dtype=object))
+
+
+@pytest.mark.parametrize('ctype', ['aig', 'xmg'])
+def test_npz_dataset_through_train_entry_and_first_batch_against_the_oracle(tmp_path, monkeypatch, ctype):
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    dev = torch.device('cuda:0')
+    import deepgate
+    from deepgate import synthetic as syn
+    from deepgate.trainer import GraphLoader
+    from deepgate.prefetch import BatchPrefetcher
+    from oracle import ref_cpu as R
+    data = str(tmp_path / 'data')
+    _write_dataset(data, ctype)
+
+    # ---- (1) the entry point: three stages of one epoch each, batches levelised on the device
+    monkeypatch.syspath_prepend(PKG_PARENT)
+    train = importlib.import_module('train')
+    train.main(['--exp_id', 'd', '--model', 'DG_AE', '--type', ctype, '--layernorm', '--batch_size', '3', '--data_dir', data, '--device_levels',
+                '--stage_epochs', '1', '1', '1', '--s_rounds', '2', '--t_rounds', '2', '--save_dir', str(tmp_path)])
+    cp = torch.load(tmp_path / 'd' / 'stage_3.pth', map_location='cpu')
+    assert cp['epoch'] == 3 and all(torch.isfinite(v).all() for v in cp['state_dict'].values() if v.is_floating_point())
+    log = [f for f in os.listdir(tmp_path / 'd') if f.startswith('log-')]
+    text = open(tmp_path / 'd' / log[0]).read()
+    assert text.count('train| Epoch') == 3 and 'nan' not in text.lower()
+
+    # ---- (2) the first batch that loop saw, rebuilt the same way (same parser cache, same loader order), with FIXED negatives and
+    #      dropout off: the three losses of the HIP path against the oracle on the host-levelised version of the same graphs
+    ds_dev = deepgate.NpzParser(data, os.path.join(data, 'graphs.npz'), os.path.join(data, 'labels.npz'), ctype, levelise=False)
+    ds_host = deepgate.NpzParser(data, os.path.join(data, 'graphs.npz'), os.path.join(data, 'labels.npz'), ctype, levelise=True)
+    tr_dev, _ = ds_dev.get_dataset()
+    tr_host, _ = ds_host.get_dataset()
+    assert [g['name'] for g in tr_dev] == [g['name'] for g in tr_host] and len(tr_dev) == 9
+    assert 'forward_level' not in tr_dev[0] and 'forward_level' in tr_host[0]
+    chunk_dev = next(GraphLoader(tr_dev, 3, True).chunks())
+    chunk_host = next(GraphLoader(tr_host, 3, True).chunks())
+    assert [g['name'] for g in chunk_dev] == [g['name'] for g in chunk_host]
+    torch.manual_seed(0)
+    enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=64, s_rounds=2, t_rounds=2, layernorm=True)
+    model = getattr(deepgate, 'dg_ae_model_' + ctype).Model(struct_encoder=enc, dim_hidden=64)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tr = deepgate.Trainer(types.SimpleNamespace(model='DG_AE'), model, training_id='o', save_dir=str(tmp_path), lr=1e-4,
+                          rc_prob_func_weight=[1.0, 4.0, 4.0], device='cuda:0', batch_size=3, distributed=False)
+    model.train()
+    gate_ids = [g for _, g in model.GATES]
+    batch = next(iter(BatchPrefetcher(iter([chunk_dev]), dev, gate_ids=gate_ids)))
+    arrays = syn.collate(chunk_host)
+    N, E = arrays['num_nodes'], arrays['edge_index'].shape[1]
+    assert int(batch.x.shape[0]) == N and torch.equal(batch.forward_level.cpu(), torch.from_numpy(arrays['forward_level']))   # device levels
+    arrays['neg_edge_index'] = syn._negative_edges(np.random.Generator(np.random.PCG64(11)), arrays['edge_index'], N, E + N)
+    batch.neg_edge_index = torch.from_numpy(arrays['neg_edge_index']).to(dev)
+    with torch.no_grad():
+        ls = tr.run_batch(batch, want_pred=False)
+    p = {k: v.clone() for k, v in sd.items()}
+    bn = {k: v.clone() for k, v in p.items() if 'running_' in k}
+    ob = R.batch_from_arrays(lambda k: arrays[k])
+    with torch.no_grad():
+        ols = R.run_batch(p, ctype, ob, training=True, bn_state=bn, p_drop=0.0, s_rounds=2, t_rounds=2,
+                          plan=R.LevelPlan(ctype, ob['edge_index'], ob['gate'], ob['forward_level']), fast=True)
+    for k in ('recon_loss', 'prob_loss', 'func_loss'):
+        a, b = float(ls[k]), float(ols[k])
+        assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)

@@ -250,3 +250,21 @@ def test_level_caches_are_dropped_when_levels_are_set_again():
     assert p._groups is None and '_heavy_seg' not in p.__dict__ and '_tagged' not in p.__dict__
     g2 = p.level_groups()
     assert len(g2) == 2
+
+
+def test_prefetcher_collates_like_collate_and_keeps_order():
+    """deepgate/prefetch.py on a CPU device: same tensors as synthetic.collate, batches in submission order, plans built."""
+    from deepgate import synthetic as syn
+    from deepgate.prefetch import BatchPrefetcher
+    graphs = [syn.make_graph('aig', 20 + 6 * (30 + 4 * i), 6, 50 + i, n_inputs=20) for i in range(6)]
+    chunks = [graphs[0:3], graphs[3:6], graphs[1:4]]
+    got = list(BatchPrefetcher(iter(chunks), 'cpu', gate_ids=[1, 2], workers=2))
+    assert len(got) == 3
+    for b, ch in zip(got, chunks):
+        ref = syn.collate(ch)
+        for k in ('x', 'edge_index', 'gate', 'forward_level', 'forward_index', 'prob', 'tt_pair_index', 'tt_sim', 'neg_edge_index'):
+            assert torch.equal(getattr(b, k), torch.from_numpy(ref[k])), k
+        assert b.graph_ptr.tolist() == ref['graph_ptr'].tolist() and b.num_graphs == 3
+        assert b._mgv_plan.has_levels and b._mgv_plan.N == ref['num_nodes']
+    skipped = next(iter(BatchPrefetcher(iter(chunks[:1]), 'cpu', skip=('neg_edge_index',))))
+    assert not hasattr(skipped, 'neg_edge_index') and not hasattr(skipped, '_mgv_plan')
