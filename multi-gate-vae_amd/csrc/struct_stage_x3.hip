@@ -65,6 +65,14 @@ __device__ __forceinline__ void stage_gemm_x3(const __bf16* wpack, const __bf16*
 // loaded once per kernel and stay in registers: the dense phase touches LDS only.
 constexpr int kThreadsF = 256;
 
+#ifndef MGV_ABLF
+#define MGV_ABLF 0           // timing ablations of diagnostic builds of the FORWARD kernel (results are wrong): 1 no MFMA, 2 light epilogue, 4 no row gathers, 8 no output stores
+#endif
+#if MGV_ABLF & 1
+#define FWD_MMA(c, ah, al, bh, bl) asm volatile("" :: "v"(ah), "v"(al), "v"(bh), "v"(bl))
+#else
+#define FWD_MMA(c, ah, al, bh, bl) mma_x3(c, ah, al, bh, bl)
+#endif
 template <int H>
 __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Args a) {
     using S = WaveSplit<H>;                 // 4 waves: column tiles first, then row tiles (mgv_common.h)
@@ -127,7 +135,11 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
             float4 acc[RPG], own[RPG], dy[RPG];
             float deg[RPG];
             int cls[RPG];
+#if MGV_ABLF & 4
+            for (int rr = 0; rr < RPG; ++rr) { acc[rr] = make_float4(0.1f * lr, 0.2f, 0.3f, 0.4f); own[rr] = acc[rr]; deg[rr] = 2.f; cls[rr] = 1; }
+#else
             tile_rows<H, RPG, false, (H == 64 ? 3 : 4)>(a, base, grp, S::GROUPS, lr, idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).idx, *idx_lds(idx_base, b).dmax(), acc, own, dy, deg, cls);
+#endif
 #pragma unroll
             for (int rr = 0; rr < RPG; ++rr) {
                 const int row = grp + rr * S::GROUPS;
@@ -155,9 +167,9 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
                 const int off = ((wr * S::RTW + i) * 16 + r) * LDP + 32 * ks + 8 * q;
                 const bf16x8 ah = ldfrag(agg_hi + off), al = ldfrag(agg_lo + off);
                 const bf16x8 hh = ldfrag(hin_hi + off), hl = ldfrag(hin_lo + off);
-                mma_x3(ar[i], ah, al, wch[ks][0], wcl[ks][0]); mma_x3(ar[i], hh, hl, wuh[ks][0], wul[ks][0]);
-                mma_x3(az[i], ah, al, wch[ks][1], wcl[ks][1]); mma_x3(az[i], hh, hl, wuh[ks][1], wul[ks][1]);
-                mma_x3(ani[i], ah, al, wch[ks][2], wcl[ks][2]); mma_x3(anh[i], hh, hl, wuh[ks][2], wul[ks][2]);
+                FWD_MMA(ar[i], ah, al, wch[ks][0], wcl[ks][0]); FWD_MMA(ar[i], hh, hl, wuh[ks][0], wul[ks][0]);
+                FWD_MMA(az[i], ah, al, wch[ks][1], wcl[ks][1]); FWD_MMA(az[i], hh, hl, wuh[ks][1], wul[ks][1]);
+                FWD_MMA(ani[i], ah, al, wch[ks][2], wcl[ks][2]); FWD_MMA(anh[i], hh, hl, wuh[ks][2], wul[ks][2]);
             }
         STAMP(2);
         __syncthreads();        // s_pre overlays the agg planes; pointers of tile t+2 are in buffer b
@@ -182,10 +194,14 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
                 const f32x4 xr = f32x4{x0[0], x1[0], x2[0], x3[0]}, xz = f32x4{x0[H], x1[H], x2[H], x3[H]}, xn = f32x4{x0[2 * H], x1[2 * H], x2[2 * H], x3[2 * H]};
                 const float* hrow = s_hin + row0 * S::LD + col;
                 const f32x4 hp = f32x4{hrow[0], hrow[S::LD], hrow[2 * S::LD], hrow[3 * S::LD]};
+#if MGV_ABLF & 2
+                const f32x4 pre = ar[i] + az[i] + ani[i] + anh[i] + hp + xr + xz + xn + deg * (bcr + bcz + bcn + bhn);
+#else
                 const f32x4 rr = sigmoid4(ar[i] + (deg * bcr + xr));
                 const f32x4 zz = sigmoid4(az[i] + (deg * bcz + xz));
                 const f32x4 nn = tanh4(ani[i] + (deg * bcn + xn) + rr * (anh[i] + bhn));
                 const f32x4 pre = nn + zz * (hp - nn);
+#endif
                 float* prow = s_pre + row0 * S::LD + col;
                 prow[0] = pre[0]; prow[S::LD] = pre[1]; prow[2 * S::LD] = pre[2]; prow[3 * S::LD] = pre[3];
             }
@@ -205,7 +221,11 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
                 const float4 g = ld4(sv.lnw + 4 * lr), bb = ld4(sv.lnb + 4 * lr);
                 v = make_float4(v.x * rstd * g.x + bb.x, v.y * rstd * g.y + bb.y, v.z * rstd * g.z + bb.z, v.w * rstd * g.w + bb.w);
             }
+#if MGV_ABLF & 8
+            if (node < a.N && v.x == 1.2345e-30f) st4(a.h_out + node * H + 4 * lr, v);
+#else
             if (node < a.N) st4(a.h_out + node * H + 4 * lr, v);
+#endif
         }
         idx_commit<kThreadsF>(idx_lds(idx_base, b).idx, ri);               // ids of tile t+2 replace this tile's
         STAMP(7);

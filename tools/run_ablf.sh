@@ -1,0 +1,7 @@
+#!/bin/bash
+# times the struct-stage FORWARD of every forward-ablation build under tools/bin (diagnostic; results of those builds are wrong by design)
+export STAGE_ONLY2=1
+for v in "$@"; do
+  echo "== forward ablation $v"
+  MGV_LIB=$PWD/tools/bin/libablf$v.so python tools/bench_stage.py 64 5 2>&1 | grep -v amdgpu.ids || exit 1
+done
