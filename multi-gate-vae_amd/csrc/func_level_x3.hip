@@ -393,31 +393,47 @@ struct OutRows {
 };
 
 // attention backward of one row from its staged source rows: alpha and d(score) of the first kInRegs in-edges come
-// back in registers (the caller stores them after it has issued the next row's loads); longer lists finish here
+// back in registers (the caller stores them after it has issued the next row's loads); longer lists finish here.
+// d(score_j) = alpha_j (t_j - sum_k alpha_k t_k), t_k = d(zbar) . x_k, is formed in the CENTRED way, alpha_j d(zbar) . (x_j - zbar)
+// with zbar = sum_k alpha_k x_k re-formed here in fp32 from the source rows: the difference of two nearly equal rows is taken
+// exactly before the dot product.  (Subtracting d(zbar) . zbar with zbar read back from its bf16 hi/lo planes — 2^-17 relative —
+// left the attention-logit parameters attn_lin / msg_k with 1e-3 of their scale in error: their gradient IS this cancelling sum.)
 template <int H>
 __device__ __forceinline__ void attn_bwd_row(const LevelX3Args& a, const InRows<H>& L, const int4& sp, const float4& us,
-                                             const float4& uf, const float4& dzs, const float4& dzf, float ci, float m,
+                                             const float4& uf, const float4& dzs, const float4& dzf, float m,
                                              float inv, int lr, float (&al)[kInRegs], float (&ds)[kInRegs], float4& gus, float4& guf) {
     constexpr int LPR = H / 4;
     const int deg = sp.y - sp.x;
+    float4 zs = zero4(), zf = zero4();
 #pragma unroll
     for (int k = 0; k < kInRegs; ++k)
         if (k < deg) {
             const float4 xs = f4(L.xs[k]), xf = f4(L.xf[k]);
             const float sc = group_sum<LPR>(dot4(us, xs) + dot4(uf, xf));
-            const float t = group_sum<LPR>(dot4(dzs, xs) + dot4(dzf, xf));
             al[k] = __expf(sc - m) * inv;
-            ds[k] = al[k] * (t - ci);
+            zs = fma4(al[k], xs, zs); zf = fma4(al[k], xf, zf);
+        }
+    for (int e = sp.x + kInRegs; e < sp.y; ++e) {          // lists longer than the staged ones (no gate type of the reference has them)
+        const int64_t j = a.in_src[e];
+        const float4 xs = ld4(a.hs + j * H + 4 * lr), xf = ld4(a.hf + j * H + 4 * lr);
+        const float al_e = __expf(group_sum<LPR>(dot4(us, xs) + dot4(uf, xf)) - m) * inv;
+        zs = fma4(al_e, xs, zs); zf = fma4(al_e, xf, zf);
+    }
+#pragma unroll
+    for (int k = 0; k < kInRegs; ++k)
+        if (k < deg) {
+            const float4 xs = f4(L.xs[k]), xf = f4(L.xf[k]);
+            const float4 cs = make_float4(xs.x - zs.x, xs.y - zs.y, xs.z - zs.z, xs.w - zs.w), cf = make_float4(xf.x - zf.x, xf.y - zf.y, xf.z - zf.z, xf.w - zf.w);
+            ds[k] = al[k] * group_sum<LPR>(dot4(dzs, cs) + dot4(dzf, cf));
             gus = fma4(ds[k], xs, gus);
             guf = fma4(ds[k], xf, guf);
         }
     for (int e = sp.x + kInRegs; e < sp.y; ++e) {
         const int64_t j = a.in_src[e];
         const float4 xs = ld4(a.hs + j * H + 4 * lr), xf = ld4(a.hf + j * H + 4 * lr);
-        const float sc = group_sum<LPR>(dot4(us, xs) + dot4(uf, xf));
-        const float t = group_sum<LPR>(dot4(dzs, xs) + dot4(dzf, xf));
-        const float al_e = __expf(sc - m) * inv;
-        const float ds_e = al_e * (t - ci);
+        const float al_e = __expf(group_sum<LPR>(dot4(us, xs) + dot4(uf, xf)) - m) * inv;
+        const float4 cs = make_float4(xs.x - zs.x, xs.y - zs.y, xs.z - zs.z, xs.w - zs.w), cf = make_float4(xf.x - zf.x, xf.y - zf.y, xf.z - zf.z, xf.w - zf.w);
+        const float ds_e = al_e * group_sum<LPR>(dot4(dzs, cs) + dot4(dzf, cf));
         if (lr == 0) { a.alpha[e] = al_e; a.dsc[e] = ds_e; }
         gus = fma4(ds_e, xs, gus);
         guf = fma4(ds_e, xf, guf);
@@ -620,8 +636,7 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
             const bf16x4 zfh = *reinterpret_cast<const bf16x4*>(z_hi + row * LDZP + H + 4 * lr), zfl = *reinterpret_cast<const bf16x4*>(z_lo + row * LDZP + H + 4 * lr);
             const float4 zs = make_float4((float)zsh[0] + (float)zsl[0], (float)zsh[1] + (float)zsl[1], (float)zsh[2] + (float)zsl[2], (float)zsh[3] + (float)zsl[3]);
             const float4 zf = make_float4((float)zfh[0] + (float)zfl[0], (float)zfh[1] + (float)zfl[1], (float)zfh[2] + (float)zfl[2], (float)zfh[3] + (float)zfl[3]);
-            const float ci = group_sum<LPR>(dot4(dzs, zs) + dot4(dzf, zf));
-            if (row < count) attn_bwd_row<H>(a, L[i], sp[i], us, uf, dzs, dzf, ci, sv.m[row], sv.inv[row], lr, al[i], ds[i], gus, guf);
+            if (row < count) attn_bwd_row<H>(a, L[i], sp[i], us, uf, dzs, dzf, sv.m[row], sv.inv[row], lr, al[i], ds[i], gus, guf);
             if (i == 0) { STAMP(12); } else { STAMP(14); }
             if (i + 1 < RPG) {
                 sp[i + 1] = ix.span[row + GROUPS];

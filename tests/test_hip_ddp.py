@@ -84,9 +84,9 @@ if rank == 0:
             continue
         err = float((g - mean).abs().max()) / sc
         worst = max(worst, err)
-        # kernel precision is pinned elsewhere (test_hip_fullsize, test_hip_model); here only the exchange is under test: the
-        # attention-logit parameters' gradient (a cancelling softmax-Jacobian sum, 100x smaller than its layer's others) gets 1e-2
-        assert err <= (1e-2 if ('attn_lin.weight' in k or 'msg_k.weight' in k) else 2e-3), (k, err)
+        # kernel precision is pinned elsewhere (test_hip_fullsize, test_hip_model); here the exchange is under test, on small
+        # (512-node) shards: one bound for every parameter
+        assert err <= 2e-3, (k, err)
     # one Adam step on the mean gradient, from zero moments: p - lr * g / (|g| + eps)
     print('DDP_OK backend=%s worst_grad_dev=%.2e' % (dist.get_backend(), worst))
 dist.barrier()
