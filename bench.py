@@ -167,10 +167,15 @@ def roofline_record(summ, table, N, E, H, step_s):
     f_step = 3.0 * (993472.0 * N + 33280.0 * E + 49152.0 * n_g)
     roof['step'] = {'bytes_8d': b_step, 'hbm_frac': b_step / step_s / 1e9 / PEAK_HBM_GBPS, 'flops_8d': f_step,
                     'mfma_frac_bf16x3': 3 * f_step / step_s / 1e12 / PEAK_BF16_MFMA_TFLOPS}
-    for fname, key in (('r02_pmc_traffic.json', 'traffic'), ('r02_pmc_mfma.json', 'mfma')):
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', fname)))
-        except (OSError, ValueError):
+    for names, key in ((('r03_pmc_traffic.json', 'r02_pmc_traffic.json'), 'traffic'), (('r03_pmc_mfma.json', 'r02_pmc_mfma.json'), 'mfma')):
+        pmc, fname = None, None
+        for fname in names:              # the newest committed counter pass
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', fname)))
+                break
+            except (OSError, ValueError):
+                continue
+        if pmc is None:
             continue
         if pmc.get('N') != N:
             continue
@@ -185,6 +190,8 @@ def roofline_record(summ, table, N, E, H, step_s):
         else:
             roof['mfma_busy'] = kern.get('mfma_busy')
             roof['valu_busy'] = kern.get('valu_busy')
+            if kern.get('coexec_share') is not None:
+                roof['valu_mfma_coexec_share'] = kern.get('coexec_share')
             roof['mfma_source'] = 'profiles/%s: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), rocprofv3 --pmc' % fname
     return roof, order
 

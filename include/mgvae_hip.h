@@ -11,7 +11,9 @@
  *   - return value: 0 = enqueued, MGV_EINVAL (-1) = bad argument, MGV_EUNSUPPORTED (-2) = unsupported
  *     size (hidden width H must be 16, 32 or 64), > 0 = hipError_t of the failed launch;
  *   - matrices are row-major fp32, node indices int32, all "gradient accumulator" outputs (dW..,
- *     db..) are ADDED to with atomics: the caller zeroes them;
+ *     db..) are ADDED to: the caller zeroes them.  On the default path (H = 64, bf16x3) the sums go through per-workgroup
+ *     slabs and a fixed-order reduction kernel (bit-identical from run to run); the exact-fp32 family, H = 32 and the
+ *     first bf16x3 backward use float atomics;
  *   - N = nodes in the batch, E = edges, H = dim_hidden, gate column blocks are ordered r,z,n like
  *     torch.nn.GRU.
  */

@@ -64,7 +64,7 @@ def busy(path, N):
     data = per_kernel(path)
     out = {'note': 'rocprofv3 --pmc pass of bench.py --steps 1 --warmup 1 (config 2); mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES): '
                    'share of SIMD cycles with the matrix pipe busy; valu_busy = 4 x SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES / 4 (quad-cycles '
-                   'of vector issue per SIMD cycle); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves parked on s_waitcnt / barriers)', 'N': N, 'kernels': {}}
+                   'of vector issue per SIMD cycle); wait_share = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves parked on s_waitcnt / barriers); coexec_share = SQ_VALU_MFMA_COEXEC_CYCLES / (4 x SQ_BUSY_CU_CYCLES)', 'N': N, 'kernels': {}}
     for name, cs in data.items():
         key = launcher_of(name)
         if key is None or 'SQ_BUSY_CU_CYCLES' not in cs:
@@ -74,13 +74,19 @@ def busy(path, N):
         cu = tot('SQ_BUSY_CU_CYCLES')
         rec = {'launches': len(big(ref)), 'SQ_BUSY_CU_CYCLES': cu}
         for c in ('SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY',
-                  'SQ_INSTS_VALU_MFMA_MOPS_BF16', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'GRBM_GUI_ACTIVE'):
+                  'SQ_VALU_MFMA_COEXEC_CYCLES', 'SQ_INSTS_VALU_MFMA_MOPS_BF16', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'GRBM_GUI_ACTIVE'):
             if c in cs:
                 rec[c] = tot(c)
         if cu and 'SQ_VALU_MFMA_BUSY_CYCLES' in rec:
             rec['mfma_busy'] = rec['SQ_VALU_MFMA_BUSY_CYCLES'] / (4.0 * cu)
         if cu and 'SQ_ACTIVE_INST_VALU' in rec:
             rec['valu_busy'] = rec['SQ_ACTIVE_INST_VALU'] * 4.0 / (4.0 * cu)
+        if cu and 'SQ_VALU_MFMA_COEXEC_CYCLES' in rec:
+            # cycles in which vector and matrix instructions execute together (MI355X_MICROARCH.md, two waves per SIMD, item 9), as a
+            # share of SIMD cycles and of the matrix pipe's busy cycles
+            rec['coexec_share'] = rec['SQ_VALU_MFMA_COEXEC_CYCLES'] / (4.0 * cu)
+            if rec.get('SQ_VALU_MFMA_BUSY_CYCLES'):
+                rec['coexec_of_mfma_busy'] = rec['SQ_VALU_MFMA_COEXEC_CYCLES'] / rec['SQ_VALU_MFMA_BUSY_CYCLES']
         if rec.get('SQ_WAVE_CYCLES') and 'SQ_WAIT_ANY' in rec:
             rec['wait_share'] = rec['SQ_WAIT_ANY'] / rec['SQ_WAVE_CYCLES']
         out['kernels'][key] = rec
