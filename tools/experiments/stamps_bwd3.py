@@ -12,8 +12,8 @@ import torch  # noqa: E402
 from deepgate import ops, synthetic as syn  # noqa: E402
 from deepgate.graph_plan import GraphPlan  # noqa: E402
 
-PH_F = ['prefetch + P1 recompute', 'P2 gru fwd + ln partials', 'wait barrier A', 'P3 ln/gru bwd + planes', 'wait barrier B']
-PH_B = ['wgrad', 'row gather', 'wait barrier A', 'weight loads + planes + indices', 'dgrad + stores', 'wait barrier B']
+PH_F = ['prefetch + P1 recompute', 'P2 gru fwd + ln partials', 'wait barrier A', 'P3 ln/gru bwd + planes', 'wait barrier B', 'dgrad Whh + stores']
+PH_B = ['wgrad', 'row gather', 'wait barrier A', 'planes + indices', 'dgrad Wc + stores', 'wait barrier B']
 
 
 def main():

@@ -77,49 +77,63 @@ __device__ __forceinline__ int ptr_prefetch3(const StageX3Args& a, int64_t tile,
     return a.ptr[n];
 }
 
-// Row loads of a 32-row tile by the 16 lane groups of the back half, two rows per group: own rows first, then the neighbour
-// lists in chunks of D slots per row (rows_chunked of struct_stage_x3_common.h for this tile size and index capacity).
+// Row loads of a 32-row tile by the 16 lane groups of the back half, two rows per group, in two steps so that the loads fly
+// while the weight-gradient MFMAs run: `rows3_issue` requests the own rows, the dY rows and the first D neighbour slots of both
+// rows (every row load only predicated: no waits, no dummy traffic); `rows3_finish` sums them and walks the remaining chunks
+// (the trip count is the tile's maximum degree: workgroup-uniform).  rows_chunked of struct_stage_x3_common.h for this tile size.
 template <int D>
-__device__ __forceinline__ void rows_chunked3(const StageX3Args& a, int64_t base, int grp, int lr, const int* s_ptr, const int* s_idx, int dmax,
-                                              bool two, float4 (&acc)[2], float4 (&own)[2], float4 (&dy)[2], float (&deg)[2], int (&cls)[2]) {
+struct Rows3 {
+    f32x4 own[2], dy[2], v0[2][D], g0[2][D];
+    int rel0[2], d[2], cls[2];
+};
+
+template <int D>
+__device__ __forceinline__ void rows3_issue(const StageX3Args& a, int64_t base, int grp, int lr, const int* s_ptr, const int* s_idx, bool two, Rows3<D>& R) {
     constexpr int H = B3::H, CAP = B3::IDXCAP;
     const int e0t = s_ptr[0];
-    int rel0[2], d[2];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int row = grp + rr * 16;
         const int p0 = s_ptr[row];
-        rel0[rr] = p0 - e0t;
-        d[rr] = s_ptr[row + 1] - p0;
+        R.rel0[rr] = p0 - e0t;
+        R.d[rr] = s_ptr[row + 1] - p0;
     }
     int j0[2][D];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-        for (int k = 0; k < D; ++k) j0[rr][k] = s_idx[min(rel0[rr] + k, CAP + 7)];
-    f32x4 v0[2][D], g0[2][D];
+        for (int k = 0; k < D; ++k) j0[rr][k] = s_idx[min(R.rel0[rr] + k, CAP + 7)];
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int64_t node = base + grp + rr * 16;
-        own[rr] = ld4(a.h_in + (a.own_idx ? (int64_t)a.own_idx[node] : node) * H + 4 * lr);
-        dy[rr] = ld4(a.gy_direct + node * H + 4 * lr);
-        cls[rr] = a.xcls[node];
+        R.own[rr] = *reinterpret_cast<const f32x4*>(a.h_in + (a.own_idx ? (int64_t)a.own_idx[node] : node) * H + 4 * lr);
+        R.dy[rr] = *reinterpret_cast<const f32x4*>(a.gy_direct + node * H + 4 * lr);
+        R.cls[rr] = a.xcls[node];
 #pragma unroll
         for (int k = 0; k < D; ++k)
-            if (k < d[rr]) {
-                v0[rr][k] = *reinterpret_cast<const f32x4*>(a.h_in + (int64_t)((unsigned)j0[rr][k] >> a.hshift) * H + 4 * lr);
-                if (two) g0[rr][k] = *reinterpret_cast<const f32x4*>(a.gy_agg + (int64_t)(j0[rr][k] & a.gmask) * H + 4 * lr);
+            if (k < R.d[rr]) {
+                R.v0[rr][k] = *reinterpret_cast<const f32x4*>(a.h_in + (int64_t)((unsigned)j0[rr][k] >> a.hshift) * H + 4 * lr);
+                if (two) R.g0[rr][k] = *reinterpret_cast<const f32x4*>(a.gy_agg + (int64_t)(j0[rr][k] & a.gmask) * H + 4 * lr);
             }
     }
+}
+
+template <int D>
+__device__ __forceinline__ void rows3_finish(const StageX3Args& a, int lr, const int* s_idx, int dmax, bool two, const Rows3<D>& R,
+                                             float4 (&acc)[2], float4 (&own)[2], float4 (&dy)[2], float (&deg)[2], int (&cls)[2]) {
+    constexpr int H = B3::H, CAP = B3::IDXCAP;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
-        deg[rr] = (float)d[rr];
+        deg[rr] = (float)R.d[rr];
+        cls[rr] = R.cls[rr];
+        own[rr] = make_float4(R.own[rr][0], R.own[rr][1], R.own[rr][2], R.own[rr][3]);
+        dy[rr] = make_float4(R.dy[rr][0], R.dy[rr][1], R.dy[rr][2], R.dy[rr][3]);
         acc[rr] = zero4();
 #pragma unroll
         for (int k = 0; k < D; ++k)
-            if (k < d[rr]) {
-                acc[rr] = add4(acc[rr], make_float4(v0[rr][k][0], v0[rr][k][1], v0[rr][k][2], v0[rr][k][3]));
-                if (two) dy[rr] = add4(dy[rr], make_float4(g0[rr][k][0], g0[rr][k][1], g0[rr][k][2], g0[rr][k][3]));
+            if (k < R.d[rr]) {
+                acc[rr] = add4(acc[rr], make_float4(R.v0[rr][k][0], R.v0[rr][k][1], R.v0[rr][k][2], R.v0[rr][k][3]));
+                if (two) dy[rr] = add4(dy[rr], make_float4(R.g0[rr][k][0], R.g0[rr][k][1], R.g0[rr][k][2], R.g0[rr][k][3]));
             }
     }
     for (int c0 = D; c0 < dmax; c0 += D) {
@@ -127,13 +141,13 @@ __device__ __forceinline__ void rows_chunked3(const StageX3Args& a, int64_t base
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-            for (int k = 0; k < D; ++k) j[rr][k] = s_idx[min(rel0[rr] + c0 + k, CAP + 7)];
+            for (int k = 0; k < D; ++k) j[rr][k] = s_idx[min(R.rel0[rr] + c0 + k, CAP + 7)];
         f32x4 v[2][D], g[2][D];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
             for (int k = 0; k < D; ++k)
-                if (c0 + k < d[rr]) {
+                if (c0 + k < R.d[rr]) {
                     v[rr][k] = *reinterpret_cast<const f32x4*>(a.h_in + (int64_t)((unsigned)j[rr][k] >> a.hshift) * H + 4 * lr);
                     if (two) g[rr][k] = *reinterpret_cast<const f32x4*>(a.gy_agg + (int64_t)(j[rr][k] & a.gmask) * H + 4 * lr);
                 }
@@ -141,23 +155,67 @@ __device__ __forceinline__ void rows_chunked3(const StageX3Args& a, int64_t base
         for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
             for (int k = 0; k < D; ++k)
-                if (c0 + k < d[rr]) {
+                if (c0 + k < R.d[rr]) {
                     acc[rr] = add4(acc[rr], make_float4(v[rr][k][0], v[rr][k][1], v[rr][k][2], v[rr][k][3]));
                     if (two) dy[rr] = add4(dy[rr], make_float4(g[rr][k][0], g[rr][k][1], g[rr][k][2], g[rr][k][3]));
                 }
     }
 }
 
+// whole gather of a tile in one go (prologue), and the generic path (partial last tile, or an index list beyond LDS: heavy rows
+// take their pre-pass sums)
+__device__ __forceinline__ bool rows3_chunked(const StageX3Args& a, int64_t base, int dmax) { return dmax < (1 << 30) && base + B3::TR <= a.N; }
+
 __device__ __forceinline__ void tile_rows3(const StageX3Args& a, int64_t base, int grp, int lr, const int* s_ptr, const int* s_idx, int dmax,
                                            float4 (&acc)[2], float4 (&own)[2], float4 (&dy)[2], float (&deg)[2], int (&cls)[2]) {
     const bool two = a.gy_agg != nullptr;
-    if (dmax < (1 << 30) && base + B3::TR <= a.N) {
-        rows_chunked3<2>(a, base, grp, lr, s_ptr, s_idx, dmax, two, acc, own, dy, deg, cls);
-    } else {                                         // partial last tile, or an index list beyond LDS (heavy rows: pre-pass sums)
+    if (rows3_chunked(a, base, dmax)) {
+        Rows3<2> R;
+        rows3_issue<2>(a, base, grp, lr, s_ptr, s_idx, two, R);
+        rows3_finish<2>(a, lr, s_idx, dmax, two, R, acc, own, dy, deg, cls);
+    } else {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int row = grp + rr * 16;
             row_generic<B3::H, true>(a, base + row, row, lr, s_ptr, two, acc[rr], own[rr], dy[rr], deg[rr], cls[rr]);
+        }
+    }
+}
+
+// dgrad of ONE matrix for the two row tiles of a 32-row tile: out[i] (+= seed) = sum over the 192 gate columns of W^T dG.
+// The six k-step fragment pairs of the wave's output column tile come from L2 (wd = hi block; lo block at +BLK): `dgrad_load3` requests
+// them a phase ahead of `dgrad_mul3` (one wave per SIMD runs this phase: nobody else hides its L2 latency).
+struct DgW3 { bf16x8 hi[6], lo[6]; };
+template <int K0, int K1>
+__device__ __forceinline__ void dgrad_load3(DgW3& w, const __bf16* wd, int lane) {
+    constexpr int BLK = 3 * B3::H * B3::H;
+#pragma unroll
+    for (int k = K0; k < K1; ++k) { w.hi[k] = ldfrag_global(wd + k * 512 + lane * 8); w.lo[k] = ldfrag_global(wd + BLK + k * 512 + lane * 8); }
+}
+// 12 steps (k-step, row tile) of 3 MFMAs; step s + 1's two operand fragments are read from LDS while step s multiplies, and the
+// scheduler may not pull later reads forward (register budget).  Steps 0-5: gate columns 0..95 (k-steps 0-2: planes r, r, z), both
+// row tiles; steps 6-11: gate columns 96..191 (k-steps 3-5: planes z, n | n*r) row tile by row tile, each finished accumulator
+// stored at once, straight from the registers: lane (r, q) holds 16 contiguous bytes of row 16 i + r.
+// pn = the n plane (Wc) or the n*r plane (Whh) of the gate-gradient buffer dgp.
+__device__ __forceinline__ void dgrad_mul3(const DgW3& w, const __bf16* dgp, const __bf16* pn, f32x4 (&dgo)[2], float* go, int64_t base, int64_t N,
+                                           int r, int q, int c0) {
+    constexpr int H = B3::H, LDP = B3::LDP, PE = B3::PE;
+    auto frag_ptr = [&](int s_) -> const __bf16* {
+        const int k = s_ < 6 ? s_ >> 1 : 3 + (s_ - 6) % 3, i = s_ < 6 ? s_ & 1 : (s_ - 6) / 3;
+        const __bf16* ph = k < 2 ? dgp : (k < 4 ? dgp + 2 * PE : pn);
+        return ph + (i * 16 + r) * LDP + 32 * (k & 1) + 8 * q;
+    };
+    bf16x8 fh[2], fl[2];
+    fh[0] = ldfrag(frag_ptr(0)); fl[0] = ldfrag(frag_ptr(0) + PE);
+#pragma unroll
+    for (int s_ = 0; s_ < 12; ++s_) {
+        if (s_ + 1 < 12) { fh[(s_ + 1) & 1] = ldfrag(frag_ptr(s_ + 1)); fl[(s_ + 1) & 1] = ldfrag(frag_ptr(s_ + 1) + PE); }
+        const int k = s_ < 6 ? s_ >> 1 : 3 + (s_ - 6) % 3, i = s_ < 6 ? s_ & 1 : (s_ - 6) / 3;
+        mma_x3(dgo[i], w.hi[k], w.lo[k], fh[s_ & 1], fl[s_ & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s_ == 8 || s_ == 11) {
+            const int64_t node = base + i * 16 + r;
+            if (node < N) *reinterpret_cast<f32x4*>(go + node * H + c0) = dgo[i];
         }
     }
 }
@@ -346,14 +404,8 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd3_x3(B3Args args
                             for (int il = 0; il < 2; ++il) {
                                 const int off = (il * 16 + r) * LDP + 32 * ks + 8 * q;
                                 const bf16x8 fh = ldfrag(xh + off), fl = ldfrag(xl + off);
-                                // term-major over the three gates: consecutive MFMAs write different accumulators (a dependent MFMA
-                                // issued right behind its producer waits for the result; one wave per SIMD runs this phase)
 #pragma unroll
-                                for (int g = 0; g < 3; ++g) oa[m][g][il] = mfma_bf16(wr_lo[m][ks][g], fh, oa[m][g][il]);
-#pragma unroll
-                                for (int g = 0; g < 3; ++g) oa[m][g][il] = mfma_bf16(wr_hi[m][ks][g], fl, oa[m][g][il]);
-#pragma unroll
-                                for (int g = 0; g < 3; ++g) oa[m][g][il] = mfma_bf16(wr_hi[m][ks][g], fh, oa[m][g][il]);
+                                for (int g = 0; g < 3; ++g) mma_x3(oa[m][g][il], wr_hi[m][ks][g], wr_lo[m][ks][g], fh, fl);
                             }
                     }
                 }
@@ -398,7 +450,15 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd3_x3(B3Args args
             STAMP(1);
             lds_barrier();                                      // (A) LayerNorm partials of tile p
             STAMP(2);
-            // ---- interval 2: P3, LayerNorm + GRU backward; gate gradients to the planes of buffer xb, dh*z to the back waves
+            // ---- interval 2: P3, LayerNorm + GRU backward; gate gradients to the planes of buffer xb, dh*z to the back waves;
+            //      the Whh fragments of tile p-1's dgrad are requested first and used behind P3
+            DgW3 wdf;
+            const bool fdg = need_dgrad && tB < ntiles;
+            if (fdg) {
+                int oz = 0;
+                asm volatile("" : "+s"(oz));                    // opaque per tile: keeps the (loop-invariant) loads inside the loop
+                dgrad_load3<0, 3>(wdf, a.wpack + 6 * BLK + wc * 6 * 512 + oz, lane0);       // k-steps 0-2 now (24 VGPRs beside P3's values)
+            }
             if (act) {
                 float lnw_acc[4] = {0.f, 0.f, 0.f, 0.f}, lnb_acc[4] = {0.f, 0.f, 0.f, 0.f};
                 __bf16* dgp = s_dg + xb * 8 * PE;
@@ -466,6 +526,20 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd3_x3(B3Args args
             }
             if ((pf0 ^ pf1 ^ pf2) == 0x7fc12345u && a.stamps) a.stamps[0] = pf0;     // keeps the prefetch loads alive; never true in practice
             STAMP(3);
+            // ---- the Whh half of tile p-1's dgrad (the back waves run the Wc half meanwhile): d h_in = dh*z + Whh^T [dr, dz, d(n*r)]
+            if (fdg) {
+                LANE_IDS3
+                {
+                    int oz = 0;
+                    asm volatile("" : "+s"(oz));
+                    dgrad_load3<3, 6>(wdf, a.wpack + 6 * BLK + wc * 6 * 512 + oz, lane);           // k-steps 3-5: P3's values are dead, used six steps from here
+                }
+                const int yb = (p + 1) & 1;
+                const __bf16* dgq = s_dg + yb * 8 * PE;
+                f32x4 dgo[2] = {s_dhz[yb * 512 + (wc * 2 + 0) * 64 + lane], s_dhz[yb * 512 + (wc * 2 + 1) * 64 + lane]};
+                dgrad_mul3(wdf, dgq, dgq + 3 * 2 * PE, dgo, a.g_direct_out, tB * TR, a.N, r, q, c0);
+            }
+            STAMP(5);
             lds_barrier();                                      // (B) gate-gradient planes and dh*z of tile p
             STAMP(4);
         }
@@ -492,8 +566,9 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd3_x3(B3Args args
             const int yb = (p + 1) & 1;                         // buffers of tile p-1 (and of tile p+1)
             const __bf16* xp = s_x + yb * 4 * PE;
             const __bf16* dgp = s_dg + yb * 8 * PE;
-            // ---- interval 1: weight gradients of tile p-1, then the row gather of tile p+1 (registers: after the weight gradients, whose
-            //      operand fragments need the registers), pointers of tile p+3
+            // ---- interval 1: weight gradients of tile p-1, then the row gather of tile p+1 (registers), pointers of tile p+3.
+            //      (Requesting the rows BEFORE the weight gradients, so that they fly meanwhile, was tried: rows3_issue / rows3_finish
+            //      exist for it; with the 112 accumulators the in-flight rows do not fit the register file: 56-77 spilled registers.)
             if (actB) {
                 // Weight gradients of both matrices over the tile's 32 rows (one k-step): the transposed fragments of the wave's two
                 // input-column tiles (and of the [deg, onehot, 1] columns) serve all three gates; the bias-type tile (gX) reuses the
@@ -501,43 +576,25 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd3_x3(B3Args args
                 const int it0 = 2 * (wc >> 1), jt0 = 2 * (wc & 1), ig = wc & 1;
                 const __bf16* xe_hi = s_xe + yb * 2 * TR * XLD;
                 const __bf16* xe_lo = xe_hi + TR * XLD;
-                // 6 steps (matrix m, gate g) of 12-15 MFMAs over 4-5 accumulators, term-major (consecutive MFMAs write different
-                // accumulators); the next step's gate-gradient fragments (and, at the matrix boundary, the next matrix' input
-                // fragments) are read while this step multiplies
-                bf16x8 xeh, xel, bh[2][2], bl[2][2], ah[2][2], al[2][2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { bh[0][j] = ldfrag_tr(xp, LDP, 0, (jt0 + j) * 16); bl[0][j] = ldfrag_tr(xp + PE, LDP, 0, (jt0 + j) * 16); }
-                auto a_plane = [&](int st) -> const __bf16* {
-                    const int m = st / 3, g = st % 3;
-                    return dgp + (g == 2 ? 2 + m : g) * 2 * PE;
-                };
+                for (int m = 0; m < 2; ++m) {
+                    const __bf16* x_hi = xp + (2 * m) * PE;
+                    const __bf16* x_lo = x_hi + PE;
+                    bf16x8 bh[2], bl[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) { ah[0][i] = ldfrag_tr(a_plane(0), LDP, 0, (it0 + i) * 16); al[0][i] = ldfrag_tr(a_plane(0) + PE, LDP, 0, (it0 + i) * 16); }
-                xeh = ldfrag_tr(xe_hi, XLD, 0, 0); xel = ldfrag_tr(xe_lo, XLD, 0, 0);
+                    for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr(x_hi, LDP, 0, (jt0 + j) * 16); bl[j] = ldfrag_tr(x_lo, LDP, 0, (jt0 + j) * 16); }
 #pragma unroll
-                for (int st = 0; st < 6; ++st) {
-                    const int m = st / 3, g = st % 3, cur = st & 1, nxt = cur ^ 1;
-                    if (st + 1 < 6) {
+                    for (int g = 0; g < 3; ++g) {
+                        const int pl = g == 2 ? 2 + m : g;
+                        const __bf16* ph = dgp + pl * 2 * PE;
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) { ah[nxt][i] = ldfrag_tr(a_plane(st + 1), LDP, 0, (it0 + i) * 16); al[nxt][i] = ldfrag_tr(a_plane(st + 1) + PE, LDP, 0, (it0 + i) * 16); }
+                        for (int i = 0; i < 2; ++i) {
+                            const bf16x8 ah = ldfrag_tr(ph, LDP, 0, (it0 + i) * 16), al = ldfrag_tr(ph + PE, LDP, 0, (it0 + i) * 16);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) mma_x3(gW[m][g][i * 2 + j], ah, al, bh[j], bl[j]);
+                            if (i == ig && (g == 2 || g == m)) mma_x3(gX[m][g == 2 ? 1 : 0], ah, al, ldfrag_tr(xe_hi, XLD, 0, 0), ldfrag_tr(xe_lo, XLD, 0, 0));
+                        }
                     }
-                    if (st == 1) {
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) { bh[1][j] = ldfrag_tr(xp + 2 * PE, LDP, 0, (jt0 + j) * 16); bl[1][j] = ldfrag_tr(xp + 3 * PE, LDP, 0, (jt0 + j) * 16); }
-                    }
-                    const bool bias = g == 2 || g == m;             // this gate's plane also feeds a bias-type tile (row tile ig)
-                    f32x4& gx = gX[m][g == 2 ? 1 : 0];
-                    const bf16x8 xah = ig ? ah[cur][1] : ah[cur][0], xal = ig ? al[cur][1] : al[cur][0];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) gW[m][g][t] = mfma_bf16(al[cur][t >> 1], bh[m][t & 1], gW[m][g][t]);
-                    if (bias) gx = mfma_bf16(xal, xeh, gx);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) gW[m][g][t] = mfma_bf16(ah[cur][t >> 1], bl[m][t & 1], gW[m][g][t]);
-                    if (bias) gx = mfma_bf16(xah, xel, gx);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) gW[m][g][t] = mfma_bf16(ah[cur][t >> 1], bh[m][t & 1], gW[m][g][t]);
-                    if (bias) gx = mfma_bf16(xah, xeh, gx);
-                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             STAMP(0);
@@ -556,23 +613,13 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd3_x3(B3Args args
             lds_barrier();                                      // (A) operand planes of tile p-1 are free
             STAMP(2);
             // ---- interval 2: operand planes of tile p+1, indices of tile p+3, dgrad of tile p-1
-            // dgrad fragments of matrix 0 (6 k-steps, hi + lo): requested first, their latency covered by the plane / index work; matrix
-            // 1's follow into the same registers as matrix 0's are used up (24 KB per wave and tile from L2)
-            bf16x8 wdA_hi[3], wdA_lo[3], wdB_hi[3], wdB_lo[3];
-            int oz = 0;
-            asm volatile("" : "+s"(oz));                        // opaque per tile: keeps the (loop-invariant) loads inside the loop
-            const __bf16* wd0 = a.wpack + 4 * BLK + wc * 6 * 512 + oz;
-            const __bf16* wd1 = a.wpack + 6 * BLK + wc * 6 * 512 + oz;
-            if (need_dgrad && actB) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { wdA_hi[k] = ldfrag_global(wd0 + k * 512 + lane0 * 8); wdA_lo[k] = ldfrag_global(wd0 + BLK + k * 512 + lane0 * 8); }
+            DgW3 wdb;
+            if (actB && need_dgrad) {
+                int oz = 0;
+                asm volatile("" : "+s"(oz));                    // opaque per tile: keeps the (loop-invariant) loads inside the loop
+                dgrad_load3<0, 6>(wdb, a.wpack + 4 * BLK + wc * 6 * 512 + oz, lane0);
             }
             if (actN) store_rows(yb, pk);
-            __builtin_amdgcn_sched_barrier(0);                  // the second half of the fragments only once the row registers are free
-            if (need_dgrad && actB) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { wdB_hi[k] = ldfrag_global(wd0 + (3 + k) * 512 + lane0 * 8); wdB_lo[k] = ldfrag_global(wd0 + BLK + (3 + k) * 512 + lane0 * 8); }
-            }
             {
                 const int* sp = idxl3(idx_base, s0).ptr;        // tile p+3's pointers (written in interval 1)
                 const int e0 = sp[0], ne = sp[TR] - e0;
@@ -587,58 +634,10 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd3_x3(B3Args args
             }
             STAMP(3);
             if (actB && need_dgrad) {
+                // the Wc half of tile p-1's dgrad: d agg = Wc^T [dr, dz, dn] (the front waves run the Whh half behind their P3)
                 LANE_IDS3
-                const int64_t base = tB * TR;
-#pragma unroll 1
-                for (int m = 0; m < 2; ++m) {
-                    f32x4 dgo[2];
-                    if (m == 0) { dgo[0] = f32x4{0.f, 0.f, 0.f, 0.f}; dgo[1] = dgo[0]; }
-                    else { dgo[0] = s_dhz[yb * 512 + (wc * 2 + 0) * 64 + lane]; dgo[1] = s_dhz[yb * 512 + (wc * 2 + 1) * 64 + lane]; }
-                    // 6 steps (one 32-deep k-step of the 192 gate columns each: planes r, r, z, z, n | n*r twice) for both row tiles, 6 MFMAs
-                    // per step; even and odd k-steps go to separate accumulators so that four independent chains alternate (a dependent
-                    // MFMA issued right behind its producer waits for it).  Step s + 1's four operand fragments are read from LDS while
-                    // step s multiplies: one wave per SIMD runs this phase, nobody else hides its LDS latency.
-                    float* go = m ? a.g_direct_out : a.g_agg_out;
-                    const __bf16* pn = dgp + (2 + m) * 2 * PE;       // n (Wc) or n*r (Whh)
-                    auto frag_ptr = [&](int k, int i) -> const __bf16* {
-                        const __bf16* ph = k < 2 ? dgp : (k < 4 ? dgp + 2 * PE : pn);
-                        return ph + (i * 16 + r) * LDP + 32 * (k & 1) + 8 * q;
-                    };
-                    f32x4 dgo2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-                    bf16x8 fh[2][2], fl[2][2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) { fh[0][i] = ldfrag(frag_ptr(0, i)); fl[0][i] = ldfrag(frag_ptr(0, i) + PE); }
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) {
-                        const int cur = k & 1, nxt = cur ^ 1;
-                        if (k + 1 < 6) {
-#pragma unroll
-                            for (int i = 0; i < 2; ++i) { fh[nxt][i] = ldfrag(frag_ptr(k + 1, i)); fl[nxt][i] = ldfrag(frag_ptr(k + 1, i) + PE); }
-                        }
-                        const bf16x8 wh = k < 3 ? wdA_hi[k % 3] : wdB_hi[k % 3], wl = k < 3 ? wdA_lo[k % 3] : wdB_lo[k % 3];
-                        f32x4& c0_ = cur ? dgo2[0] : dgo[0];
-                        f32x4& c1_ = cur ? dgo2[1] : dgo[1];
-                        c0_ = mfma_bf16(wl, fh[cur][0], c0_); c1_ = mfma_bf16(wl, fh[cur][1], c1_);
-                        c0_ = mfma_bf16(wh, fl[cur][0], c0_); c1_ = mfma_bf16(wh, fl[cur][1], c1_);
-                        c0_ = mfma_bf16(wh, fh[cur][0], c0_); c1_ = mfma_bf16(wh, fh[cur][1], c1_);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (k == 2 && m == 0) {
-#pragma unroll
-                            for (int kk = 0; kk < 3; ++kk) { wdA_hi[kk] = ldfrag_global(wd1 + kk * 512 + lane * 8); wdA_lo[kk] = ldfrag_global(wd1 + BLK + kk * 512 + lane * 8); }
-                        }
-                    }
-                    // outputs straight from the registers: lane (r, q) holds 16 contiguous bytes of row 16 i + r
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int64_t node = base + i * 16 + r;
-                        const f32x4 o = dgo[i] + dgo2[i];
-                        if (node < a.N) *reinterpret_cast<f32x4*>(go + node * H + c0) = o;
-                    }
-                    if (m == 0) {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) { wdB_hi[k] = ldfrag_global(wd1 + (3 + k) * 512 + lane * 8); wdB_lo[k] = ldfrag_global(wd1 + BLK + (3 + k) * 512 + lane * 8); }
-                    }
-                }
+                f32x4 dgo[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                dgrad_mul3(wdb, dgp, dgp + 2 * 2 * PE, dgo, a.g_agg_out, tB * TR, a.N, r, q, c0);
             }
             idxl3(idx_base, s0).idx[bt] = ri;                   // tile p+3's indices (requested at the head of this interval)
             STAMP(4);
