@@ -120,9 +120,9 @@ def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
     return h_out
 
 
-# backward kernel of the bf16x3 half round at H = 64: '2' = register-resident recompute weights, transposed products,
-# slab-reduced (deterministic) parameter gradients (struct_stage_bwd2_x3.hip); '1' = the first kernel (A/B measurements)
-STAGE_BWD = os.environ.get('MGV_STAGE_BWD', '2')
+# The bf16x3 half-round backward at H = 64 is struct_stage_bwd2_x3.hip (register-resident recompute weights, transposed products,
+# slab-reduced deterministic parameter gradients); the first kernel (struct_stage_x3.hip) serves H = 32 only (tools/bench_stage.py
+# still times both through the C ABI).
 TABLE_MODE = os.environ.get('MGV_TABLE_MODE', '1') != '0'     # half round 2 of an encoder reads the (degree, class) table directly
 _WS = {}
 
@@ -162,7 +162,7 @@ def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
     if table_own is not None:
         N = table_own.numel()
     check(gy_direct, F32, 'gy_direct'); check(gy_agg, F32, 'gy_agg')
-    if use_x3(H) and H == 64 and STAGE_BWD == '2':
+    if use_x3(H) and H == 64:
         g_direct = torch.empty(N, H, dtype=F32, device=h_in.device) if need_input_grad else None
         g_agg = torch.empty(N, H, dtype=F32, device=h_in.device) if need_input_grad else None
         wpack = stage_wpack(Wc, Whh) if wpack is None else wpack
@@ -218,7 +218,7 @@ class StructEncoderFn(torch.autograd.Function):
         first = plan.first_stage_classes(xcls) if (FIRST_STAGE_TABLE and rounds > 0 and N > 0) else None
         h = None if first is not None else torch.ones(N, H, dtype=F32, device=dev)
         # table mode for the half round after the table one: bf16x3 H = 64 kernels, node ids and table rows fit a tagged 32-bit entry
-        table_mode = first is not None and use_x3(H) and H == 64 and STAGE_BWD == '2' and N < (1 << 24) and first[1] <= 256 and TABLE_MODE
+        table_mode = first is not None and use_x3(H) and H == 64 and N < (1 << 24) and first[1] <= 256 and TABLE_MODE
         states = []
         for _ in range(rounds):
             for rev in (False, True):

@@ -5,8 +5,8 @@ properties of the path.
   * relabelling the nodes (a random permutation of ids, edges/levels/labels carried along) leaves the
     three losses unchanged and permutes the embeddings;
   * a batch is the disjoint union of its graphs: per-graph embeddings do not depend on batch mates;
-  * a train step on config 3 (MIG, 3-input MAJ gates) and config 5 (XMG, 256k-node graphs, 5 aggregators)
-    shapes runs and produces finite losses and gradients.
+  * a train step on config 3 (MIG, 3-input MAJ gates) and config 5 (XMG, 256k-node graphs, 5 aggregators) at their full
+    per-GPU batch runs and produces finite losses and gradients.
 """
 import types
 
@@ -97,8 +97,10 @@ def test_graphs_of_a_batch_do_not_interact():
     assert float((hf3[sl] - hf1).abs().max()) <= 1e-5 * max(1.0, float(hf1.abs().max()))
 
 
-@pytest.mark.parametrize('cfg,ctype,batch', [(3, 'mig', 8), (5, 'xmg', 2)])
+@pytest.mark.parametrize('cfg,ctype,batch', [(3, 'mig', 64), (5, 'xmg', 16)])
 def test_train_step_on_other_baseline_shapes(cfg, ctype, batch):
+    """BASELINE configs 3 and 5 at their FULL per-GPU batch (64 x 65,536-node MIGs; 16 x 262,144-node XMGs, 240 levels, five
+    aggregators): a train step runs, losses / gradients / parameters are finite, every edge and negative is counted."""
     dev = _dev()
     import deepgate
     from deepgate import synthetic as syn
