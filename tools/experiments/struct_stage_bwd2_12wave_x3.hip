@@ -67,12 +67,31 @@ __device__ __forceinline__ float quad_rows_sum(float v) {      // sum over the f
     return v;
 }
 
+// ldfrag_tr (mgv_x3.h) with the lane passed in: the back waves re-derive it per k-step behind an opaque copy of the thread id, so
+// that the ~60 loop-invariant LDS addresses of the weight-gradient phase are not hoisted out of the tile loop and spilled
+__device__ __forceinline__ bf16x8 ldfrag_tr_l(const __bf16* plane, int ld, int k0, int c0, int lane) {
+    const int q = lane >> 4, i16 = lane & 15;
+    const __bf16* p = plane + (k0 + 8 * q + (i16 >> 2)) * ld + c0 + 4 * (i16 & 3);
+    const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4v*)p);
+    const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4v*)(p + 4 * ld));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 struct B2Args {
     StageX3Args s;
     float* slab;        // [gridDim][B2::SLAB]
 };
 
-__global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args) {
+// Workgroup = 8 FRONT waves (two per SIMD: wave (wc, m) as described above, every phase but the weight gradients) + 4 BACK waves (the
+// third wave of every SIMD; back wave wc holds the weight-gradient accumulators of BOTH matrices for its 2x2 block of output tiles).
+// The back waves pass the tile's barriers idle and run the tile's weight gradients between barrier (4) — gate-gradient planes complete —
+// and the next tile's barrier (0) — operand planes rewritten —, i.e. beside the front waves' dgrad, output stores and the next tile's
+// row gather: a third of the MFMA work leaves the front waves' critical path and overlaps with their memory wait.  12 waves = 3 per
+// SIMD: 168 VGPRs per wave.
+constexpr int kBackWaves = 4;
+constexpr int kThreadsB2 = kThreadsX3 + 64 * kBackWaves;
+
+__global__ __launch_bounds__(kThreadsB2) void k_struct_stage_bwd2_x3(B2Args args) {
     const StageX3Args& a = args.s;
     constexpr int H = B2::H, LDP = B2::LDP, LDF = B2::LDF, BLK = 3 * H * H, PE = kTileRows * B2::LDP;   // PE: elements of one plane
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -95,7 +114,8 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
     float* s_lnacc = reinterpret_cast<float*>(smem_raw + B2::o_lnacc);
 
     const int tid = threadIdx.x;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wc = w & 3, m = w >> 2;     // wave-uniform: scalar registers
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wc = w & 3, m = (w >> 2) & 1;     // wave-uniform: scalar registers
+    const bool back = w >= kNW;                                                          // waves 8-11: weight gradients only
     // Lane-derived indices are re-derived per phase behind an opaque copy of the thread id (LANE_IDS): otherwise every LDS
     // address of the loop body is hoisted out of the tile loop and the ~40 loop-invariant address registers are spilled.
 #define LANE_IDS \
@@ -118,29 +138,92 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
     const int wd_off = (4 + 2 * m) * BLK + wc * 6 * 512;
 
     const __bf16 *wr_hi_p = wr_hi_p_, *wr_lo_p = wr_lo_p_;
-    // ---- persistent accumulators
-    f32x4 gW[3][4];                         // 2x2 block of this wave's matrix, per gate (wgrad_blk_x3)
-    f32x4 gX[2];                            // bias-type gradients of planes p = m (pp 0) and 2 + m (pp 1), gate-column tile wc
     // LayerNorm affine gradients: summed over the 16 nodes of a lane group in registers, then added by one lane to this wave's
     // own LDS slots (program order: deterministic); 8 VGPRs less to keep alive across the whole kernel
-    for (int i = tid; i < kNW * 2 * 16; i += kThreadsX3) s_lnacc[i] = 0.f;
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) gW[g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gX[0] = gX[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < kNW * 2 * 16; i += kThreadsB2) s_lnacc[i] = 0.f;
 
     // (static priority for the second-dispatched half, waves 4-7, only swaps which half waits at the barriers: measured zero-sum)
     const TileSeq seq = tile_seq(ntiles, a.xcd);
-    int rp = ptr_prefetch(a, seq.at(0), ntiles);
-    if (tid <= kTileRows) idx_lds(idx_base, 0).ptr[tid] = rp;
-    __syncthreads();
+    int rp = 0;
     int ri[kIdxCap / kThreadsX3];
-    idx_prefetch<kThreadsX3>(a, idx_lds(idx_base, 0).ptr, ri);
-    idx_commit<kThreadsX3>(idx_lds(idx_base, 0).idx, ri);
-    tile_dmax(idx_lds(idx_base, 0).ptr, idx_lds(idx_base, 0).dmax());
-    rp = ptr_prefetch(a, seq.at(1), ntiles);
+    if (!back) {
+        rp = ptr_prefetch(a, seq.at(0), ntiles);
+        if (tid <= kTileRows) idx_lds(idx_base, 0).ptr[tid] = rp;
+    }
     __syncthreads();
+    if (!back) {
+        idx_prefetch<kThreadsX3>(a, idx_lds(idx_base, 0).ptr, ri);
+        idx_commit<kThreadsX3>(idx_lds(idx_base, 0).idx, ri);
+        tile_dmax(idx_lds(idx_base, 0).ptr, idx_lds(idx_base, 0).dmax());
+        rp = ptr_prefetch(a, seq.at(1), ntiles);
+    }
+    __syncthreads();
+    if (back) {
+        // =================================================================================== BACK waves: weight gradients
+        f32x4 gW[2][3][4];                      // 2x2 block of output tiles per matrix (0: Wc against the neighbour sums, 1: Whh against
+        f32x4 gX[2][2];                         // the own rows) and gate; bias-type tiles: planes p = m (pp 0) and 2 + m (pp 1), tile wc
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) gW[mm][g][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gX[mm][0] = gX[mm][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const int it0 = 2 * (wc >> 1), jt0 = 2 * (wc & 1), ig = wc & 1;
+        for (int it = 0; seq.at(it) < ntiles; ++it) {
+            __syncthreads();                    // (0)
+            __syncthreads();                    // (1)
+            __syncthreads();                    // (2)
+            __syncthreads();                    // (3)
+            __syncthreads();                    // (4) gate-gradient planes of this tile are complete; the operand planes stay until the next (0)
+            // Weight gradients of both matrices and all three gates over the tile's two 32-row k-steps: the transposed fragments of the
+            // wave's two input-column tiles (and of the [deg, onehot, 1] columns) are read once per k-step and matrix and serve every
+            // gate; the bias-type tile (gX) reuses the gate-gradient fragment the 2x2 block loads anyway (its row tile wc is
+            // it0 + (wc & 1), its planes p = 2 pp + m are among the three matrix m reads).
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int k0 = 32 * half;
+                int tl = tid; asm volatile("" : "+v"(tl));
+                const int ln = tl & 63;
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm) {
+                    const __bf16* x_hi = mm ? hin_hi : agg_hi;
+                    const __bf16* x_lo = mm ? hin_lo : agg_lo;
+                    bf16x8 bh[2], bl[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr_l(x_hi, LDP, k0, (jt0 + j) * 16, ln); bl[j] = ldfrag_tr_l(x_lo, LDP, k0, (jt0 + j) * 16, ln); }
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        const int p = g == 2 ? 2 + mm : g;
+                        const __bf16* ph = s_dg + p * 2 * PE;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const bf16x8 ah = ldfrag_tr_l(ph, LDP, k0, (it0 + i) * 16, ln), al = ldfrag_tr_l(ph + PE, LDP, k0, (it0 + i) * 16, ln);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) mma_x3(gW[mm][g][i * 2 + j], ah, al, bh[j], bl[j]);
+                            if (i == ig && (g == 2 || g == mm)) mma_x3(gX[mm][g == 2 ? 1 : 0], ah, al, ldfrag_tr_l(xe_hi, XLD, k0, 0, ln), ldfrag_tr_l(xe_lo, XLD, k0, 0, ln));
+                            // 112 of the wave's 168 registers are accumulators: operand fragments of later steps must not be pulled forward
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+        }
+        // flush: per-workgroup slab, lane-linear float4 slots (k_struct_stage_bwd2_reduce knows the mapping: block m * 4 + wc)
+        float* slab = args.slab + (int64_t)blockIdx.x * B2::SLAB;
+#pragma unroll
+        for (int mm = 0; mm < 2; ++mm) {
+            f32x4* sw = reinterpret_cast<f32x4*>(slab) + ((mm * 4 + wc) * B2::SLOTS) * 64 + lane0;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sw[(g * 4 + t) * 64] = gW[mm][g][t];
+            sw[12 * 64] = gX[mm][0];
+            sw[13 * 64] = gX[mm][1];
+        }
+    } else {
+    // =================================================================================== FRONT waves: everything else
     int b = 0;
     // recompute fragments of the first tile; every later tile's set is requested while the previous tile's outputs drain
     bf16x8 wr_hi[2][3], wr_lo[2][3];
@@ -390,51 +473,22 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             }
         }
         if ((pf0 ^ pf1) == 0x7fc12345u && a.stamps) a.stamps[0] = pf0;     // keeps the prefetch loads alive; never true in practice
+        // the first half of this wave's dgrad fragments leaves L2 in front of barrier (4) (12 KB per wave and tile, 24 VGPRs at a time)
+        bf16x8 wd_hi[3], wd_lo[3];
+        int oz = 0;
+        asm volatile("" : "+s"(oz));                        // opaque per tile: keeps the (loop-invariant) loads inside the loop
+        const __bf16* wd_p = a.wpack + wd_off + oz;
+        if (need_dgrad) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { wd_hi[k] = ldfrag_global(wd_p + k * 512 + lane0 * 8); wd_lo[k] = ldfrag_global(wd_p + BLK + k * 512 + lane0 * 8); }
+        }
         STAMP(6);
         __syncthreads();                                    // (4) gate-gradient planes, dh*z hand-off, next tile's indices
         STAMP(7);
-        // ---- P4. weight gradients and dgrad, interleaved in two halves: each half's six dgrad fragments leave L2 in front of
-        //      weight-gradient MFMAs that cover the latency (12 KB per wave and tile; 24 VGPRs at a time)
+        // ---- P4. dgrad (the weight gradients of this tile run on the back waves meanwhile)
         f32x4 dgo[4];
         {
             LANE_IDS
-            const __bf16* x_hi = m ? hin_hi : agg_hi;
-            const __bf16* x_lo = m ? hin_lo : agg_lo;
-            // Weight gradients of all three gates in ONE pass over the tile's two 32-row k-steps: the transposed fragments of the
-            // wave's two input-column tiles (and of the [deg, onehot, 1] columns) are read once per k-step and serve every gate;
-            // the bias-type tile (gX) reuses the gate-gradient fragment the 2x2 block loads anyway (its row tile wc is it0 + (wc & 1),
-            // its planes p = 2 pp + m are among the three this wave's matrix reads).  The dgrad fragments of each half leave L2 in
-            // front of one k-step of these MFMAs.
-            const int it0 = 2 * (wc >> 1), jt0 = 2 * (wc & 1), ig = wc & 1;
-            bf16x8 wd_hi[3], wd_lo[3];
-            int oz = 0;
-#if !(MGV_ABL & 16)
-            asm volatile("" : "+s"(oz));                    // opaque per tile: keeps the (loop-invariant) loads inside the loop
-#endif
-            const __bf16* wd_p = a.wpack + wd_off + oz;
-            if (need_dgrad) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { wd_hi[k] = ldfrag_global(wd_p + k * 512 + lane * 8); wd_lo[k] = ldfrag_global(wd_p + BLK + k * 512 + lane * 8); }
-            }
-#pragma unroll 1
-            for (int half = 0; half < 2; ++half) {
-                const int k0 = 32 * half;
-                bf16x8 bh[2], bl[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr(x_hi, LDP, k0, (jt0 + j) * 16); bl[j] = ldfrag_tr(x_lo, LDP, k0, (jt0 + j) * 16); }
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    const int p = g == 2 ? 2 + m : g;
-                    const __bf16* ph = s_dg + p * 2 * PE;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const bf16x8 ah = ldfrag_tr(ph, LDP, k0, (it0 + i) * 16), al = ldfrag_tr(ph + PE, LDP, k0, (it0 + i) * 16);
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) mma_x3(gW[g][i * 2 + j], ah, al, bh[j], bl[j]);
-                        if (i == ig && (g == 2 || g == m)) mma_x3(gX[g == 2 ? 1 : 0], ah, al, ldfrag_tr(xe_hi, XLD, k0, 0), ldfrag_tr(xe_lo, XLD, k0, 0));
-                    }
-                }
-            }
             STAMP(8);
             if (need_dgrad) {
                 // seeds of the accumulators (after the weight gradients: 16 registers less to carry through them)
@@ -488,17 +542,9 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
         // only after the next tile's barrier (1)
     }
     STAMP_FLUSH(a);
+    }   // front waves
 
-    // ---- flush: per-workgroup slab, lane-linear float4 slots (k_struct_stage_bwd2_reduce knows the mapping)
-    LANE_IDS
     float* slab = args.slab + (int64_t)blockIdx.x * B2::SLAB;
-    f32x4* sw = reinterpret_cast<f32x4*>(slab) + (w * B2::SLOTS) * 64 + lane;
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) sw[(g * 4 + t) * 64] = gW[g][t];
-    sw[12 * 64] = gX[0];
-    sw[13 * 64] = gX[1];
     // LayerNorm affine gradients: the two row halves (m) in a fixed order
     __syncthreads();
     if (tid < 2 * H) {
@@ -581,7 +627,7 @@ int launch_bwd2_x3(const StageX3Args& s, float* workspace, int64_t workspace_flo
     const int grid = grid_for(ntiles, 1);
     if (workspace == nullptr || workspace_floats < (int64_t)grid * B2::SLAB) return MGV_EINVAL;
     B2Args a{s, workspace};
-    hipLaunchKernelGGL(k_struct_stage_bwd2_x3, dim3(grid), dim3(kThreadsX3), B2::bytes, st, a);
+    hipLaunchKernelGGL(k_struct_stage_bwd2_x3, dim3(grid), dim3(kThreadsB2), B2::bytes, st, a);
     return launch_stage_slab_reduce(s, workspace, grid, st);
 }
 
