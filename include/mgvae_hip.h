@@ -199,6 +199,39 @@ int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t
                           int heavy_active_n, const int32_t* heavy_nodes, const int32_t* heavy_node_seg_ptr, const int32_t* heavy_seg_e0,
                           const int32_t* heavy_seg_e1, const int32_t* heavy_lvl_k_ptr_host, const int32_t* heavy_lvl_seg_ptr_host,
                           float* heavy_ws, int skip_active_longer_than, void* stream);
+
+/* Rounds >= 2 of the functional sweep (dg_ae_model_aig.py:70-97 with num_rounds > 1: every gate is updated again, its GRU starting
+ * from the node's state of the previous round; bf16x3, H in {32, 64}).  Same arguments as the two entries above plus
+ *   gh[N][3H]     W_hh h_prev + b_hh of each node's own aggregator (r, z, n blocks), formed by the caller with mgv_linear_*;
+ *   h_prev[N][H]  the previous round's states; `hf` must hold a copy of them on entry (rows of never-updated nodes stay);
+ *   zero_bhh      [T][3H] zeros (b_hh is inside gh);
+ * backward: d_gh[N][3H] (rows of updated nodes written) and g_hprev[N][H] = dh * z (the caller zeroes it: other rows are not written);
+ * the dbhh accumulator receives nothing meaningful (its gradient comes from the caller's linear kernels). */
+int mgv_func_sweep_round_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                          const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
+                          const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
+                          const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
+                          const void* wpack_bf16, const float* bvc, const float* bih, const float* zero_bhh,
+                          const float* gh, const float* h_prev, void* stream);
+int mgv_func_sweep_round_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                          const int32_t* order, const int32_t* order_span, int64_t n_active,
+                          const int32_t* tile_start, const int32_t* tile_count, const int32_t* tile_slot,
+                          const int32_t* slot_tiles, const int32_t* slot_tile_ptr_host, const int32_t* in_ptr,
+                          const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                          const int32_t* out_slot, const uint8_t* gslot, const float* hs, const float* hf,
+                          const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
+                          const float* bhh, const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc,
+                          float* d_attn_u, float* dWvc, float* dbvc, float* dbih, float* dbhh, float* scratch,
+                          int64_t scratch_elems,
+                          int skip_inactive_longer_than /* > 0: never-updated nodes with more consumers are left to mgv_sweep_pull_heavy */,
+                          /* updated gates with more than skip_active_longer_than consumers (an inverter of a clock-like input), ordered by
+                           * (level, id): nodes[K], node_seg_ptr[K+1], segment bounds, per-level ranges of nodes and segments as HOST arrays
+                           * [num_levels + 1] (GraphPlan.heavy_segments(True, active_by_level=True)); heavy_ws: (K + segments) * 2H floats.
+                           * Their pulls run per level by whole workgroups in front of the level's kernel.  0 / NULLs: none. */
+                          int heavy_active_n, const int32_t* heavy_nodes, const int32_t* heavy_node_seg_ptr, const int32_t* heavy_seg_e0,
+                          const int32_t* heavy_seg_e1, const int32_t* heavy_lvl_k_ptr_host, const int32_t* heavy_lvl_seg_ptr_host,
+                          float* heavy_ws, int skip_active_longer_than,
+                          const float* gh, const float* h_prev, float* d_gh, float* g_hprev, void* stream);
 /* ghs rows of the heavy never-updated nodes (primary inputs driving thousands of gates): consumer lists in segments, one workgroup
  * each (GraphPlan.heavy_segments(reverse=True, inactive_only=True)); partial_ws: S * H floats */
 int mgv_sweep_pull_heavy(int H, int K, const int32_t* nodes, const int32_t* node_seg_ptr, int S, const int32_t* seg_e0,

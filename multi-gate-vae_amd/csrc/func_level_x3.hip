@@ -50,6 +50,10 @@ struct LevelX3Args {
     // updated gates with more than skip_active consumers (an inverter of a clock-like input): their pull comes from a per-level
     // pre-pass (k_pull_heavy_seg<H, true>): heavy_nodes[heavy_k0 .. heavy_k1) = this level's, ascending ids; heavy_pull[k][2H]
     int skip_active; int heavy_k0; int heavy_k1; const int32_t* heavy_nodes; const float* heavy_pull;
+    // rounds >= 2 of the sweep (dg_ae_model_aig.py:70-97: the GRU of a node starts from the node's state of the previous round):
+    // gh[node][3H] = W_hh h_prev + b_hh of the node's own aggregator (formed by the linear kernels before the sweep, the caller
+    // passes bhh = 0 here), hprev[node][H]; the backward leaves d(gh)[node][3H] and d(h_prev)[node][H] = dh * z.  NULL in round 1.
+    const float* gh; const float* hprev; float* dgh; float* ghprev;
 };
 
 // kLW waves over a (64 rows) x COLS output: across column tiles first, then row tiles
@@ -266,7 +270,7 @@ __device__ __forceinline__ void lvl_gemm_x3(const __bf16* wslot, const __bf16* z
     }
 }
 
-template <int H>
+template <int H, bool HID = false>
 __global__ __launch_bounds__(kLT, 4) void k_level_fwd_x3(LevelX3Args a) {
     using S = SplitL<H>;
     using M = LvlSmem<H>;
@@ -328,10 +332,21 @@ __global__ __launch_bounds__(kLT, 4) void k_level_fwd_x3(LevelX3Args a) {
             for (int e = 0; e < 4; ++e) {
                 const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
                 const float sa = sv.sa[row];
-                const float rr = sigmoidf_(ar[i][e] + sa * bvr + cr);
-                const float zz = sigmoidf_(az[i][e] + sa * bvz + cz);
-                const float nn = tanhf_(an[i][e] + sa * bvn + cn + rr * bhn);
-                s_o[row * LDO + col] = (1.0f - zz) * nn;        // h0 = 0
+                if constexpr (HID) {
+                    // previous-round state: gh = W_hh h + b_hh per gate block, h' = (1 - z) n + z h
+                    const int64_t node = ix.node[row];
+                    float gr = 0.f, gz = 0.f, gn = 0.f, hp = 0.f;
+                    if (node >= 0) { const float* g_ = a.gh + node * 3 * H + col; gr = g_[0]; gz = g_[H]; gn = g_[2 * H]; hp = a.hprev[node * H + col]; }
+                    const float rr = sigmoidf_(ar[i][e] + sa * bvr + cr + gr);
+                    const float zz = sigmoidf_(az[i][e] + sa * bvz + cz + gz);
+                    const float nn = tanhf_(an[i][e] + sa * bvn + cn + rr * (gn + bhn));
+                    s_o[row * LDO + col] = (1.0f - zz) * nn + zz * hp;
+                } else {
+                    const float rr = sigmoidf_(ar[i][e] + sa * bvr + cr);
+                    const float zz = sigmoidf_(az[i][e] + sa * bvz + cz);
+                    const float nn = tanhf_(an[i][e] + sa * bvn + cn + rr * bhn);
+                    s_o[row * LDO + col] = (1.0f - zz) * nn;        // h0 = 0
+                }
             }
     }
     STAMP(5);
@@ -446,7 +461,7 @@ __device__ __forceinline__ void attn_bwd_row(const LevelX3Args& a, const InRows<
 // weight gradient is therefore not formed here: the tile leaves its gate gradients dG[pos][3H] and its zbar rows
 // z[pos][2H] (pos = position in `order`) for k_sweep_wgrad_x3, and adds its small parameter gradients (gu, dbvc,
 // dbih, dbhh) with plain loads/stores into the slab that workgroup b of EVERY level owns per slot.
-template <int H>
+template <int H, bool HID = false>
 __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
     using S = SplitL<H>;
     using S2 = SplitL<2 * H>;
@@ -554,13 +569,33 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
             for (int e = 0; e < 4; ++e) {
                 const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
                 const float sa = sv.sa[row];
-                const float rr = sigmoidf_(ar[i][e] + sa * bvr + cr);
-                const float zz = sigmoidf_(az[i][e] + sa * bvz + cz);
-                const float nn = tanhf_(an[i][e] + sa * bvn + cn + rr * bhn);
-                const float dh = s_dh[row * LDO + col];
-                const float dan = dh * (1.0f - zz) * (1.0f - nn * nn);
-                const float daz = -dh * nn * zz * (1.0f - zz);
-                const float dar = dan * bhn * rr * (1.0f - rr);
+                float dar, daz, dan, rr;
+                if constexpr (HID) {
+                    const int64_t node = ix.node[row];
+                    float gr = 0.f, gz = 0.f, gn = 0.f, hp = 0.f;
+                    if (node >= 0) { const float* g_ = a.gh + node * 3 * H + col; gr = g_[0]; gz = g_[H]; gn = g_[2 * H]; hp = a.hprev[node * H + col]; }
+                    rr = sigmoidf_(ar[i][e] + sa * bvr + cr + gr);
+                    const float zz = sigmoidf_(az[i][e] + sa * bvz + cz + gz);
+                    const float ghn = gn + bhn;
+                    const float nn = tanhf_(an[i][e] + sa * bvn + cn + rr * ghn);
+                    const float dh = s_dh[row * LDO + col];
+                    dan = dh * (1.0f - zz) * (1.0f - nn * nn);
+                    daz = dh * (hp - nn) * zz * (1.0f - zz);
+                    dar = dan * ghn * rr * (1.0f - rr);
+                    if (node >= 0) {
+                        float* d_ = a.dgh + node * 3 * H + col;
+                        d_[0] = dar; d_[H] = daz; d_[2 * H] = dan * rr;       // d(gh): the caller's linear kernels turn it into d(W_hh), d(b_hh), d(h_prev)
+                        a.ghprev[node * H + col] = dh * zz;                   // the direct path to the previous state
+                    }
+                } else {
+                    rr = sigmoidf_(ar[i][e] + sa * bvr + cr);
+                    const float zz = sigmoidf_(az[i][e] + sa * bvz + cz);
+                    const float nn = tanhf_(an[i][e] + sa * bvn + cn + rr * bhn);
+                    const float dh = s_dh[row * LDO + col];
+                    dan = dh * (1.0f - zz) * (1.0f - nn * nn);
+                    daz = -dh * nn * zz * (1.0f - zz);
+                    dar = dan * bhn * rr * (1.0f - rr);
+                }
                 ar[i][e] = dar; az[i][e] = daz; an[i][e] = dan;
                 b_r += dar; b_z += daz; b_n += dan; h_n += dan * rr;
                 v_r += sa * dar; v_z += sa * daz; v_n += sa * dan;
@@ -897,19 +932,24 @@ __global__ __launch_bounds__(256) void k_level_small_reduce(const float* wslab, 
     *dst += (p[0] + p[1]) + (p[2] + p[3]);
 }
 
-template <int H>
-int launch_level_x3(bool bwd, const LevelX3Args& a, int ntiles, hipStream_t st) {
+template <int H, bool HID>
+int launch_level_x3_v(bool bwd, const LevelX3Args& a, int ntiles, hipStream_t st) {
     using M = LvlSmem<H>;
     if (bwd) {
         static bool set_b = false;
-        if (!set_b) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_bwd_x3<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_b = true; }
-        hipLaunchKernelGGL(k_level_bwd_x3<H>, dim3(ntiles), dim3(kLT), M::bwd_bytes, st, a);
+        if (!set_b) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_bwd_x3<H, HID>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_b = true; }
+        hipLaunchKernelGGL((k_level_bwd_x3<H, HID>), dim3(ntiles), dim3(kLT), M::bwd_bytes, st, a);
     } else {
         static bool set_f = false;
-        if (!set_f) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_fwd_x3<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_f = true; }
-        hipLaunchKernelGGL(k_level_fwd_x3<H>, dim3(ntiles), dim3(kLT), M::fwd_bytes, st, a);
+        if (!set_f) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_fwd_x3<H, HID>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_f = true; }
+        hipLaunchKernelGGL((k_level_fwd_x3<H, HID>), dim3(ntiles), dim3(kLT), M::fwd_bytes, st, a);
     }
     MGV_LAUNCH_RET();
+}
+
+template <int H>
+int launch_level_x3(bool bwd, const LevelX3Args& a, int ntiles, hipStream_t st) {
+    return a.gh != nullptr ? launch_level_x3_v<H, true>(bwd, a, ntiles, st) : launch_level_x3_v<H, false>(bwd, a, ntiles, st);
 }
 
 template <int H>
@@ -943,17 +983,20 @@ extern "C" int mgv_sweep_zero_inactive(int H, int64_t N, const uint8_t* gslot, f
     MGV_LAUNCH_RET();
 }
 
-extern "C" int mgv_func_sweep_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                                     const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
-                                     const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
-                                     const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
-                                     const void* wpack_bf16, const float* bvc, const float* bih, const float* bhh, void* stream) {
+static int sweep_fwd_x3_impl(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                             const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
+                             const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
+                             const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
+                             const void* wpack_bf16, const float* bvc, const float* bih, const float* bhh,
+                             const float* gh, const float* h_prev, void* stream) {
     MGV_CHECK_ARG(N >= 0 && T >= 1 && T <= mgv::kMaxSlots && num_levels >= 0 && level_tile_ptr_host && hs && hf && attn_u && wpack_bf16 && bvc && bih && bhh && in_ptr);
     mgv::LevelX3Args a{};
     MGV_SET_LVL_STAMPS(a);
     a.N = N; a.T = T; a.order = order; a.order_span = order_span; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot;
     a.in_ptr = in_ptr; a.in_src = in_src; a.hs = hs; a.hf = hf; a.attn_u = attn_u; a.wpack = static_cast<const __bf16*>(wpack_bf16);
     a.bvc = bvc; a.bih = bih; a.bhh = bhh;
+    MGV_CHECK_ARG((gh == nullptr) == (h_prev == nullptr));
+    a.gh = gh; a.hprev = h_prev;
     hipStream_t st = static_cast<hipStream_t>(stream);
     for (int lv = 1; lv < num_levels; ++lv) {
         const int t0 = level_tile_ptr_host[lv], t1 = level_tile_ptr_host[lv + 1];
@@ -971,7 +1014,27 @@ extern "C" int mgv_func_sweep_fwd_x3(int H, int64_t N, int T, int num_levels, co
     return MGV_OK;
 }
 
-extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+extern "C" int mgv_func_sweep_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                                     const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
+                                     const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
+                                     const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
+                                     const void* wpack_bf16, const float* bvc, const float* bih, const float* bhh, void* stream) {
+    return sweep_fwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, tile_start, tile_count, tile_slot, in_ptr, in_src, hs, hf,
+                             attn_u, wpack_bf16, bvc, bih, bhh, nullptr, nullptr, stream);
+}
+
+extern "C" int mgv_func_sweep_round_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                                           const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
+                                           const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
+                                           const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
+                                           const void* wpack_bf16, const float* bvc, const float* bih, const float* zero_bhh,
+                                           const float* gh, const float* h_prev, void* stream) {
+    MGV_CHECK_ARG(gh && h_prev);
+    return sweep_fwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, tile_start, tile_count, tile_slot, in_ptr, in_src, hs, hf,
+                             attn_u, wpack_bf16, bvc, bih, zero_bhh, gh, h_prev, stream);
+}
+
+static int sweep_bwd_x3_impl(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
                                      const int32_t* order, const int32_t* order_span, int64_t n_active,
                                      const int32_t* tile_start, const int32_t* tile_count, const int32_t* tile_slot,
                                      const int32_t* slot_tiles, const int32_t* slot_tile_ptr_host, const int32_t* in_ptr,
@@ -983,7 +1046,8 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
                                      int64_t scratch_elems, int skip_inactive_longer_than, int heavy_active_n,
                                      const int32_t* heavy_nodes, const int32_t* heavy_node_seg_ptr, const int32_t* heavy_seg_e0,
                                      const int32_t* heavy_seg_e1, const int32_t* heavy_lvl_k_ptr_host,
-                                     const int32_t* heavy_lvl_seg_ptr_host, float* heavy_ws, int skip_active_longer_than, void* stream) {
+                                     const int32_t* heavy_lvl_seg_ptr_host, float* heavy_ws, int skip_active_longer_than,
+                                     const float* gh, const float* h_prev, float* d_gh, float* g_hprev, void* stream) {
     MGV_CHECK_ARG(N >= 0 && T >= 1 && T <= mgv::kMaxSlots && num_levels >= 0 && n_active >= 0 && level_tile_ptr_host && hs && hf &&
                   attn_u && wpack_bf16 && bvc && bih && bhh);
     MGV_CHECK_ARG(in_ptr && out_ptr && gslot && ghf && ghs && dzb && d_attn_u && dWvc && dbvc && dbih && dbhh);
@@ -996,6 +1060,8 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
     a.out_ptr = out_ptr; a.out_dst = out_dst; a.out_slot = out_slot; a.gslot = gslot;
     a.ghf = ghf; a.ghs = ghs; a.dzb = dzb; a.alpha = alpha; a.dsc = dsc; a.d_attn_u = d_attn_u; a.dWvc = dWvc; a.dbvc = dbvc;
     a.dbih = dbih; a.dbhh = dbhh; a.skip_inactive = skip_inactive_longer_than;
+    MGV_CHECK_ARG(gh == nullptr ? (!h_prev && !d_gh && !g_hprev) : (h_prev && d_gh && g_hprev));
+    a.gh = gh; a.hprev = h_prev; a.dgh = d_gh; a.ghprev = g_hprev;
     MGV_CHECK_ARG(heavy_active_n >= 0 && (heavy_active_n == 0 || (heavy_nodes && heavy_node_seg_ptr && heavy_seg_e0 && heavy_seg_e1 &&
                                                                 heavy_lvl_k_ptr_host && heavy_lvl_seg_ptr_host && heavy_ws && skip_active_longer_than > 0)));
     a.skip_active = skip_active_longer_than; a.heavy_nodes = heavy_nodes; a.heavy_pull = heavy_ws;      // [K][2H], then the segment partials
@@ -1058,6 +1124,46 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
         default: return MGV_EUNSUPPORTED;
     }
     MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                                     const int32_t* order, const int32_t* order_span, int64_t n_active,
+                                     const int32_t* tile_start, const int32_t* tile_count, const int32_t* tile_slot,
+                                     const int32_t* slot_tiles, const int32_t* slot_tile_ptr_host, const int32_t* in_ptr,
+                                     const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                     const int32_t* out_slot, const uint8_t* gslot, const float* hs, const float* hf,
+                                     const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
+                                     const float* bhh, const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc,
+                                     float* d_attn_u, float* dWvc, float* dbvc, float* dbih, float* dbhh, float* scratch,
+                                     int64_t scratch_elems, int skip_inactive_longer_than, int heavy_active_n,
+                                     const int32_t* heavy_nodes, const int32_t* heavy_node_seg_ptr, const int32_t* heavy_seg_e0,
+                                     const int32_t* heavy_seg_e1, const int32_t* heavy_lvl_k_ptr_host,
+                                     const int32_t* heavy_lvl_seg_ptr_host, float* heavy_ws, int skip_active_longer_than, void* stream) {
+    return sweep_bwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, n_active, tile_start, tile_count, tile_slot, slot_tiles,
+                             slot_tile_ptr_host, in_ptr, in_src, out_ptr, out_dst, out_slot, gslot, hs, hf, attn_u, wpack_bf16, bvc, bih, bhh, ghf, ghs, dzb,
+                             alpha, dsc, d_attn_u, dWvc, dbvc, dbih, dbhh, scratch, scratch_elems, skip_inactive_longer_than, heavy_active_n, heavy_nodes,
+                             heavy_node_seg_ptr, heavy_seg_e0, heavy_seg_e1, heavy_lvl_k_ptr_host, heavy_lvl_seg_ptr_host, heavy_ws, skip_active_longer_than, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int mgv_func_sweep_round_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                                     const int32_t* order, const int32_t* order_span, int64_t n_active,
+                                     const int32_t* tile_start, const int32_t* tile_count, const int32_t* tile_slot,
+                                     const int32_t* slot_tiles, const int32_t* slot_tile_ptr_host, const int32_t* in_ptr,
+                                     const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
+                                     const int32_t* out_slot, const uint8_t* gslot, const float* hs, const float* hf,
+                                     const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
+                                     const float* bhh, const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc,
+                                     float* d_attn_u, float* dWvc, float* dbvc, float* dbih, float* dbhh, float* scratch,
+                                     int64_t scratch_elems, int skip_inactive_longer_than, int heavy_active_n,
+                                     const int32_t* heavy_nodes, const int32_t* heavy_node_seg_ptr, const int32_t* heavy_seg_e0,
+                                     const int32_t* heavy_seg_e1, const int32_t* heavy_lvl_k_ptr_host,
+                                     const int32_t* heavy_lvl_seg_ptr_host, float* heavy_ws, int skip_active_longer_than,
+                                     const float* gh, const float* h_prev, float* d_gh, float* g_hprev, void* stream) {
+    MGV_CHECK_ARG(gh && h_prev && d_gh && g_hprev);
+    return sweep_bwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, n_active, tile_start, tile_count, tile_slot, slot_tiles,
+                             slot_tile_ptr_host, in_ptr, in_src, out_ptr, out_dst, out_slot, gslot, hs, hf, attn_u, wpack_bf16, bvc, bih, bhh, ghf, ghs, dzb,
+                             alpha, dsc, d_attn_u, dWvc, dbvc, dbih, dbhh, scratch, scratch_elems, skip_inactive_longer_than, heavy_active_n, heavy_nodes,
+                             heavy_node_seg_ptr, heavy_seg_e0, heavy_seg_e1, heavy_lvl_k_ptr_host, heavy_lvl_seg_ptr_host, heavy_ws, skip_active_longer_than, gh, h_prev, d_gh, g_hprev, stream);
 }
 
 // ghs[nodes[k]] = the pull of heavy never-updated nodes (skipped by mgv_func_sweep_bwd_x3 when skip_inactive_longer_than > 0), their

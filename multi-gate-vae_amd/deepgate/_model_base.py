@@ -131,12 +131,31 @@ class FunctionalModel(nn.Module):
         hs_in = self._hs_pass if self._hs_pass is not None else hs
         self._hs_pass = None
         hf = ops.FuncSweepFn.apply(plan, hs_in, *self._sweep_params())
-        # further rounds (dg_ae_model_aig.py:70; the reference default and train.py use 1): every node is updated again from its
-        # previous state.  Compatibility path composed from PyTorch device operators, level by level — correct, not tuned.
+        # further rounds (dg_ae_model_aig.py:70; the reference default and train.py use 1): every gate is updated again, its GRU
+        # starting from the gate's previous state.  On the HIP level kernels (ops.FuncSweepRoundFn) whenever the bf16x3 sweep serves
+        # this width; otherwise (exact-fp32 mode, H = 16, batches with high fan-out lists) the round composed from PyTorch operators.
         for _ in range(self.num_rounds - 1):
-            mods = [(getattr(self, 'aggr_%s_func' % n), getattr(self, 'update_%s_func' % n)) for n, _ in self.GATES]
-            hf = ExtraRoundFn.apply(plan, mods, hs_in, hf, *[p for a, g in mods for p in _round_params(a, g)])
+            if ops.sweep_round_on_hip(plan, self.dim_hidden):
+                au, Wvc, bvc, bih, _ = self._sweep_params()
+                hf = ops.FuncSweepRoundFn.apply(plan, hs_in, hf, self._round_gh(plan, hf), au, Wvc, bvc, bih)
+            else:
+                mods = [(getattr(self, 'aggr_%s_func' % n), getattr(self, 'update_%s_func' % n)) for n, _ in self.GATES]
+                hf = ExtraRoundFn.apply(plan, mods, hs_in, hf, *[p for a, g in mods for p in _round_params(a, g)])
         return hs, hf
+
+    def _round_gh(self, plan, hf):
+        """gh[N, 3H] = W_hh h_prev + b_hh with each updated node's OWN aggregator weights (nn.GRU gate order r, z, n), on the linear
+        kernels: the rows of every gate type are gathered, multiplied per gate block and put back (index moves only)."""
+        H = self.dim_hidden
+        gh = torch.zeros(hf.shape[0], 3 * H, dtype=hf.dtype, device=hf.device)
+        for (name, _), idx in zip(self.GATES, plan.slot_nodes()):
+            if idx.numel() == 0:
+                continue
+            gru = getattr(self, 'update_%s_func' % name)
+            rows = hf.index_select(0, idx)
+            parts = [ops.linear(rows, gru.weight_hh_l0[g * H:(g + 1) * H], gru.bias_hh_l0[g * H:(g + 1) * H]) for g in range(3)]
+            gh = gh.index_copy(0, idx, torch.cat(parts, dim=1))
+        return gh
 
     def pred_prob(self, hf, seed=None):
         return self.readout_prob(hf, clamp01=True, seed=seed)

@@ -250,6 +250,7 @@ class GraphPlan:
         self._groups = None
         self.__dict__.pop('_heavy_seg', None)
         self.__dict__.pop('_tagged', None)
+        self.__dict__.pop('_slot_nodes', None)
 
     def _set_levels_hip(self, gate, forward_level, gate_ids):
         from . import _hip
@@ -381,6 +382,14 @@ class GraphPlan:
                 setattr(self, k, v.to(device))
         self.device = torch.device(device)
         return self
+
+    def slot_nodes(self):
+        """Node ids (int64, ascending) of every aggregator slot's updated nodes: what a round >= 2 of the sweep gathers to form
+        W_hh h_prev per gate type.  Cached per levelisation."""
+        if '_slot_nodes' not in self.__dict__:
+            assert self.has_levels
+            self._slot_nodes = [torch.nonzero(self.gslot == s_).reshape(-1) for s_ in range(self.num_slots)]
+        return self._slot_nodes
 
     def level_groups(self):
         """[(nodes, slot, src, seg)] per (level, gate type) group in ascending level order, as int64 device tensors: the group's

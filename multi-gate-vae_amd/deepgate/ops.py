@@ -357,7 +357,7 @@ class LinearFn(torch.autograd.Function):
         x1, x2, W = ctx.saved_tensors
         if gy is None:                     # only the pass-through output was used
             return g_pass, None, None, None, None
-        gy = _rowmajor(gy)
+        gy = _rowmajor(gy).contiguous()      # (a column slice of a wider gradient, e.g. behind torch.cat, arrives row-strided)
         N, K1 = x1.shape
         K2 = 0 if x2 is None else x2.shape[1]
         M = W.shape[0]
@@ -434,6 +434,90 @@ def gather_sum(h, nbr_ptr=None, nbr_idx=None, plan=None, reverse=False):
 _SWEEP_BWD_EVENT = None
 
 
+def _sweep_bwd_prep(plan, T, H, dev):
+    """Scratch and heavy-list arguments of mgv_func_sweep_bwd_x3 / mgv_func_sweep_round_bwd_x3."""
+    ltp = plan.level_tile_ptr
+    widest = max([ltp[i + 1] - ltp[i] for i in range(1, len(ltp) - 1)] + [1])
+    # rows for the deferred weight gradient, small-gradient slabs of the widest level, 256 rows of weight-gradient partials
+    scratch = torch.empty(plan.n_active * 5 * H + widest * T * 11 * H + 256 * 6 * H * H, dtype=F32, device=dev)
+    stp = (_hip.ctypes.c_int32 * len(plan.slot_tile_ptr))(*plan.slot_tile_ptr)
+    hv = plan.heavy_segments(True, inactive_only=True)
+    hav = plan.heavy_segments(True, active_by_level=True)      # updated gates with very long consumer lists
+    if hav is None:
+        ha = (0, None, None, None, None, None, None, None, 0)
+    else:
+        i32a = _hip.ctypes.c_int32
+        kp = (i32a * len(hav['lvl_k_ptr']))(*hav['lvl_k_ptr'])
+        sp_ = (i32a * len(hav['lvl_seg_ptr']))(*hav['lvl_seg_ptr'])
+        need = (hav['K'] + hav['S']) * 2 * H          # its own buffer: it must outlive the launcher call's other scratch users
+        hws = _WS.get(('heavy_active', str(dev)))
+        if hws is None or hws.numel() < need:
+            hws = _WS[('heavy_active', str(dev))] = torch.empty(need, dtype=F32, device=dev)
+        ha = (hav['K'], ptr(hav['nodes']), ptr(hav['node_seg_ptr']), ptr(hav['seg_e0']), ptr(hav['seg_e1']), kp, sp_, ptr(hws), plan.HEAVY_ROW)
+    return scratch, stp, hv, ha
+
+
+def sweep_round_on_hip(plan, H):
+    """Rounds >= 2 of the sweep run on the level kernels (mgv_func_sweep_round_*_x3) when the bf16x3 sweep serves this width and
+    the batch has no high fan-out list on the sweep's pull paths (those keep the PyTorch-composed round, _model_base.ExtraRoundFn)."""
+    if not (use_x3(H) and H in (32, 64) and os.environ.get('MGV_SWEEP_X3', '1') != '0' and plan.device.type == 'cuda'):
+        return False
+    return plan.heavy_segments(True, inactive_only=True) is None and plan.heavy_segments(True, active_by_level=True) is None
+
+
+class FuncSweepRoundFn(torch.autograd.Function):
+    """Round r >= 2 of the functional sweep (dg_ae_model_aig.py:70-97 with num_rounds > 1) on the HIP level kernels:
+    hf_new = sweep(hs, hf_prev) where every updated gate's GRU starts from its previous state.  `gh` [N, 3H] = W_hh h_prev + b_hh of
+    each node's own aggregator, formed by the caller with ops.linear (so that autograd carries its gradient to W_hh, b_hh and
+    h_prev through the linear kernels); the level kernels add it to the gate pre-activations, mix z * h_prev into the new state and
+    leave d(gh) and dh * z on the way back."""
+
+    @staticmethod
+    def forward(ctx, plan, hs, hprev, gh, attn_u, Wvc, bvc, bih):
+        hsd = check(hs.detach().contiguous(), F32, 'hs')
+        hp = check(hprev.detach().contiguous(), F32, 'h_prev')
+        ghd = check(gh.detach().contiguous(), F32, 'gh')
+        N, H = hsd.shape
+        par = [check(t.detach().contiguous(), F32, 'sweep parameter') for t in (attn_u, Wvc, bvc, bih)]
+        T = par[0].shape[0]
+        assert plan.has_levels and plan.num_slots == T and plan.N == N and ghd.shape == (N, 3 * H) and hp.shape == (N, H)
+        ltp = (_hip.ctypes.c_int32 * len(plan.level_tile_ptr))(*plan.level_tile_ptr)
+        wpack = sweep_wpack(par[1])
+        zb = torch.zeros(T, 3 * H, dtype=F32, device=hsd.device)
+        hf = hp.clone()                      # never-updated rows keep their state; every updated row is rewritten by its level
+        _hip.call('mgv_func_sweep_round_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.order_span),
+                  ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
+                  ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(zb), ptr(ghd), ptr(hp))
+        ctx.plan, ctx.par, ctx.ltp, ctx.wpack, ctx.zb = plan, par, ltp, wpack, zb
+        ctx.save_for_backward(hsd, hf, hp, ghd)
+        return hf
+
+    @staticmethod
+    def backward(ctx, ghf):
+        plan, par = ctx.plan, ctx.par
+        hs, hf, hp, ghd = ctx.saved_tensors
+        N, H = hs.shape
+        T = par[0].shape[0]
+        dev = hs.device
+        ghf = check(ghf.contiguous(), F32, 'ghf')
+        ghs = torch.empty(N, H, dtype=F32, device=dev)
+        dzb = torch.empty(N, 2 * H, dtype=F32, device=dev)
+        alpha = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
+        dsc = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
+        grads = [torch.zeros_like(t) for t in par] + [torch.zeros_like(ctx.zb)]      # the last one (dbhh) is not meaningful here
+        d_gh = torch.zeros(N, 3 * H, dtype=F32, device=dev)          # rows of never-updated nodes stay zero
+        g_hprev = torch.zeros(N, H, dtype=F32, device=dev)           # (their states are constants of round 1: no gradient to carry)
+        scratch, stp, hv, ha = _sweep_bwd_prep(plan, T, H, dev)
+        assert hv is None and ha[0] == 0, 'high fan-out lists take the composed round (sweep_round_on_hip)'
+        _hip.call('mgv_func_sweep_round_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.order_span),
+                  plan.n_active, ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.slot_tiles), stp,
+                  ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr), ptr(plan.out_dst), ptr(plan.out_slot),
+                  ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]), ptr(ctx.wpack), ptr(par[2]), ptr(par[3]), ptr(ctx.zb),
+                  ptr(ghf), ptr(ghs), ptr(dzb), ptr(alpha), ptr(dsc), *[ptr(g) for g in grads], ptr(scratch),
+                  scratch.numel(), 0, *ha, ptr(ghd), ptr(hp), ptr(d_gh), ptr(g_hprev))
+        return (None, ghs, g_hprev, d_gh, grads[0], grads[1], grads[2], grads[3])
+
+
 class FuncSweepFn(torch.autograd.Function):
     """hf = sweep(hs) over levels 1..L-1 (dg_ae_model_aig.py:70-97); parameters are the per-slot
     composed tensors attn_u [T,2H], Wvc [T,3H,2H], bvc/bih/bhh [T,3H]."""
@@ -484,24 +568,7 @@ class FuncSweepFn(torch.autograd.Function):
         dsc = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
         grads = [torch.zeros_like(t) for t in par]
         if ctx.wpack is not None:
-            ltp = plan.level_tile_ptr
-            widest = max([ltp[i + 1] - ltp[i] for i in range(1, len(ltp) - 1)] + [1])
-            # rows for the deferred weight gradient, small-gradient slabs of the widest level, 256 rows of weight-gradient partials
-            scratch = torch.empty(plan.n_active * 5 * H + widest * T * 11 * H + 256 * 6 * H * H, dtype=F32, device=dev)
-            stp = (_hip.ctypes.c_int32 * len(plan.slot_tile_ptr))(*plan.slot_tile_ptr)
-            hv = plan.heavy_segments(True, inactive_only=True)
-            hav = plan.heavy_segments(True, active_by_level=True)      # updated gates with very long consumer lists
-            if hav is None:
-                ha = (0, None, None, None, None, None, None, None, 0)
-            else:
-                i32a = _hip.ctypes.c_int32
-                kp = (i32a * len(hav['lvl_k_ptr']))(*hav['lvl_k_ptr'])
-                sp_ = (i32a * len(hav['lvl_seg_ptr']))(*hav['lvl_seg_ptr'])
-                need = (hav['K'] + hav['S']) * 2 * H          # its own buffer: it must outlive the launcher call's other scratch users
-                hws = _WS.get(('heavy_active', str(dev)))
-                if hws is None or hws.numel() < need:
-                    hws = _WS[('heavy_active', str(dev))] = torch.empty(need, dtype=F32, device=dev)
-                ha = (hav['K'], ptr(hav['nodes']), ptr(hav['node_seg_ptr']), ptr(hav['seg_e0']), ptr(hav['seg_e1']), kp, sp_, ptr(hws), plan.HEAVY_ROW)
+            scratch, stp, hv, ha = _sweep_bwd_prep(plan, T, H, dev)
             _hip.call('mgv_func_sweep_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.order_span),
                       plan.n_active, ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.slot_tiles), stp,
                       ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr), ptr(plan.out_dst), ptr(plan.out_slot),

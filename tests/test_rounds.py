@@ -1,7 +1,8 @@
-"""Functional sweep with num_rounds > 1 (dg_ae_model_aig.py:70) and the stand-alone TFMlpAggr call (arch/tfmlp.py:31-46):
-the compatibility path composed from PyTorch operators.  CPU: the level operator against the reference's own fixture
-(g3_ops: TFMlpAggr + GRU from a NON-zero state, outputs and every gradient), the round function against a plain autograd
-restatement of the reference's level loop.  GPU: a two-round model against the pinned oracle."""
+"""Functional sweep with num_rounds > 1 (dg_ae_model_aig.py:70) and the stand-alone TFMlpAggr call (arch/tfmlp.py:31-46).
+CPU: the composed level operator (the fallback of the exact-fp32 mode, H = 16 and high fan-out batches) against the reference's own
+fixture (g3_ops: TFMlpAggr + GRU from a NON-zero state, outputs and every gradient), the composed round function against a plain
+autograd restatement of the reference's level loop.  GPU: two- and three-round models against the pinned oracle THROUGH THE HIP
+level kernels (mgv_func_sweep_round_*_x3: the composed round must not run)."""
 import os
 import types
 
@@ -111,17 +112,21 @@ def test_round_function_equals_plain_autograd(ctype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('H,ctype', [(64, 'aig'), (32, 'xmg')])
-def test_two_round_model_against_the_oracle(H, ctype):
+@pytest.mark.parametrize('H,ctype,rounds', [(64, 'aig', 2), (32, 'xmg', 2), (64, 'mig', 3)])
+def test_two_round_model_against_the_oracle(H, ctype, rounds, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip('needs a GPU')
     import deepgate
-    from deepgate import synthetic as syn
+    from deepgate import _model_base, synthetic as syn
     from oracle import ref_cpu as R
+
+    def composed_round_must_not_run(*a, **k):
+        raise AssertionError('rounds >= 2 left the HIP level kernels')
+    monkeypatch.setattr(_model_base.ExtraRoundFn, 'apply', composed_round_must_not_run)
     dev = torch.device('cuda:0')
     torch.manual_seed(9)
     enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=H, s_rounds=2, t_rounds=2, layernorm=True)
-    model = getattr(deepgate, 'dg_ae_model_' + ctype).Model(struct_encoder=enc, num_rounds=2, dim_hidden=H)
+    model = getattr(deepgate, 'dg_ae_model_' + ctype).Model(struct_encoder=enc, num_rounds=rounds, dim_hidden=H)
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0
@@ -137,7 +142,7 @@ def test_two_round_model_against_the_oracle(H, ctype):
     p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running_' not in k else v.clone()) for k, v in sd.items()}
     bn = {k: v.clone() for k, v in p.items() if 'running_' in k}
     ob = R.batch_from_arrays(lambda k: arrays[k])
-    ols = R.run_batch(p, ctype, ob, training=True, bn_state=bn, p_drop=0.0, s_rounds=2, t_rounds=2, num_rounds=2)
+    ols = R.run_batch(p, ctype, ob, training=True, bn_state=bn, p_drop=0.0, s_rounds=2, t_rounds=2, num_rounds=rounds)
     ols1 = R.run_batch({k: v.detach() for k, v in p.items()}, ctype, ob, training=True, bn_state={k: v.clone() for k, v in bn.items()},
                        p_drop=0.0, s_rounds=2, t_rounds=2, num_rounds=1)
     assert abs(float(ols['prob_loss'].detach()) - float(ols1['prob_loss'].detach())) > 1e-6      # the second round does something
