@@ -232,6 +232,17 @@ int mgv_func_sweep_round_bwd_x3(int H, int64_t N, int T, int num_levels, const i
                           const int32_t* heavy_seg_e1, const int32_t* heavy_lvl_k_ptr_host, const int32_t* heavy_lvl_seg_ptr_host,
                           float* heavy_ws, int skip_active_longer_than,
                           const float* gh, const float* h_prev, float* d_gh, float* g_hprev, void* stream);
+/* ---- stand-alone TFMlpAggr (arch/tfmlp.py:31-46: an edge-list call outside the levelised sweep).  Attention pooling over a CSR by
+ * destination: zbar[i][W] = sum_j alpha_ij x[j], alpha = softmax over i's sources of u . x[j] (PyG softmax: exp(s - max) / (sum + 1e-16));
+ * the module's message is W_v zbar + b_v [deg > 0] (mgv_linear_*).  W = row width (2 * dim_hidden) in {32, 64, 128};
+ * mstat / inv [N]: the softmax statistics the backward re-uses.  Backward: dx [N][W] and du [W] are ADDED to with float atomics
+ * (the caller zeroes them; this entry is not on the train step). */
+int mgv_attn_pool_fwd(int W, int64_t N, const int32_t* in_ptr, const int32_t* in_src, const float* x, const float* u,
+                      float* zbar, float* mstat, float* inv, void* stream);
+int mgv_attn_pool_bwd(int W, int64_t N, const int32_t* in_ptr, const int32_t* in_src, const float* x, const float* u,
+                      const float* zbar, const float* mstat, const float* inv, const float* dzbar, float* dx, float* du,
+                      void* stream);
+
 /* ghs rows of the heavy never-updated nodes (primary inputs driving thousands of gates): consumer lists in segments, one workgroup
  * each (GraphPlan.heavy_segments(reverse=True, inactive_only=True)); partial_ws: S * H floats */
 int mgv_sweep_pull_heavy(int H, int K, const int32_t* nodes, const int32_t* node_seg_ptr, int S, const int32_t* seg_e0,

@@ -52,9 +52,20 @@ class TFMlpAggr(nn.Module):
         v = torch.nn.functional.linear(x_src, self.msg_v.weight, self.msg_v.bias) * alpha.unsqueeze(1)
         return torch.zeros(n, out, dtype=x_src.dtype, device=x_src.device).index_add(0, seg, v)
 
-    def forward(self, x, edge_index, edge_attr=None, **kwargs):
+    def forward(self, x, edge_index, edge_attr=None, plan=None, **kwargs):
         """Stand-alone edge-list call (tfmlp.py:31-35): [N, out] messages, zero rows for nodes without in-edges.
-        Composed from PyTorch device operators (differentiable); the train step does not come through here — inside a
-        Model the aggregation runs in the levelised sweep kernels."""
-        src, dst = edge_index[0].long(), edge_index[1].long()
-        return self.attend(x.index_select(0, src), dst, x.shape[0])
+        On the device: attention pooling of the source rows (csrc/attn_pool.hip) followed by the value Linear,
+        W_v (sum_j alpha_j x_j) + b_v [deg > 0] = sum_j alpha_j (W_v x_j + b_v).  `plan` = a GraphPlan of edge_index saves
+        building the CSR.  On a CPU tensor (host tests) the same arithmetic composed from PyTorch operators."""
+        if not x.is_cuda:
+            src, dst = edge_index[0].long(), edge_index[1].long()
+            return self.attend(x.index_select(0, src), dst, x.shape[0])
+        from .. import ops
+        from ..graph_plan import GraphPlan
+        if plan is None:
+            plan = GraphPlan(edge_index, x.shape[0])
+        out = self.msg_k.weight.shape[0]
+        u = self.attn_lin.weight[0, out:] @ self.msg_k.weight
+        zbar = ops.AttnPoolFn.apply(x, u, plan)
+        has_in = (plan.in_ptr[1:] > plan.in_ptr[:-1]).to(x.dtype).unsqueeze(1)
+        return ops.linear(zbar, self.msg_v.weight) + has_in * self.msg_v.bias

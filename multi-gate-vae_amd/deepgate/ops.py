@@ -428,6 +428,34 @@ def gather_sum(h, nbr_ptr=None, nbr_idx=None, plan=None, reverse=False):
     return agg, deg
 
 
+class AttnPoolFn(torch.autograd.Function):
+    """zbar[i] = sum_j softmax_j(u . x_j) x_j over i's in-edges (csrc/attn_pool.hip): the stand-alone TFMlpAggr call."""
+
+    @staticmethod
+    def forward(ctx, x, u, plan):
+        xd = check(x.detach().contiguous(), F32, 'x')
+        ud = check(u.detach().contiguous(), F32, 'u')
+        N, W = xd.shape
+        if W not in (32, 64, 128) or ud.numel() != W:
+            raise ValueError('attention pooling: row width %d (u: %d) is not one of 32 / 64 / 128' % (W, ud.numel()))
+        zbar = torch.empty_like(xd)
+        m, inv = torch.empty(N, dtype=F32, device=xd.device), torch.empty(N, dtype=F32, device=xd.device)
+        _hip.call('mgv_attn_pool_fwd', W, N, ptr(plan.in_ptr), ptr(plan.in_src), ptr(xd), ptr(ud), ptr(zbar), ptr(m), ptr(inv))
+        ctx.plan = plan
+        ctx.save_for_backward(xd, ud, zbar, m, inv)
+        return zbar
+
+    @staticmethod
+    def backward(ctx, gz):
+        xd, ud, zbar, m, inv = ctx.saved_tensors
+        N, W = xd.shape
+        g = _rowmajor(gz).contiguous()
+        dx, du = torch.zeros_like(xd), torch.zeros_like(ud)
+        _hip.call('mgv_attn_pool_bwd', W, N, ptr(ctx.plan.in_ptr), ptr(ctx.plan.in_src), ptr(xd), ptr(ud), ptr(zbar), ptr(m), ptr(inv),
+                  ptr(g), ptr(dx), ptr(du))
+        return dx, du, None
+
+
 # ------------------------------------------------------------------------------------------------
 # levelised functional sweep
 # ------------------------------------------------------------------------------------------------

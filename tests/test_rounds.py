@@ -162,3 +162,83 @@ def test_two_round_model_against_the_oracle(H, ctype, rounds, monkeypatch):
             g, ref = g[:, H:], ref[:, H:]
         scale = max(1e-6, float(np.abs(ref).max()))
         np.testing.assert_allclose(g, ref, rtol=2e-3, atol=1e-3 * scale + 5e-6, err_msg='grad ' + k)
+
+
+@pytest.mark.gpu
+def test_standalone_aggregator_on_hip_matches_the_reference_fixture():
+    """TFMlpAggr.forward on a device tensor = csrc/attn_pool.hip + the linear kernels; outputs and every gradient of the
+    reference's own fixture (aggregator + GRU from a non-zero state).  The composed PyTorch form must not run."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from deepgate.arch.tfmlp import TFMlpAggr
+    z = np.load(os.path.join(GOLDEN, 'g3_ops.npz'))
+    H = z['lvl_hprev'].shape[1]
+    dev = torch.device('cuda:0')
+    aggr = TFMlpAggr(2 * H, H)
+    aggr.load_state_dict({k[len('lvl_aggr_'):]: torch.tensor(z[k]) for k in z.files if k.startswith('lvl_aggr_')})
+    gru = torch.nn.GRU(H, H)
+    gru.load_state_dict({k[len('lvl_gru_'):]: torch.tensor(z[k]) for k in z.files if k.startswith('lvl_gru_')})
+    aggr, gru = aggr.to(dev), gru.to(dev)
+    aggr.attend = None                       # the composed form is the CPU path
+    ei = torch.tensor(z['lvl_edge_index'])
+    nodes = torch.tensor(z['lvl_nodes'])
+    keep = torch.isin(ei[1], nodes)
+    ns = torch.tensor(z['lvl_node_state'], device=dev, requires_grad=True)
+    hprev = torch.tensor(z['lvl_hprev'], device=dev, requires_grad=True)
+    msg = aggr(ns, ei[:, keep].to(dev))
+    nd = nodes.to(dev)
+    close(msg[nd], z['lvl_msg'], msg='stand-alone TFMlpAggr.forward (HIP)')
+    others = torch.ones(ns.shape[0], dtype=torch.bool, device=dev)
+    others[nd] = False
+    assert float(msg[others].detach().abs().max()) == 0.0
+    hnew = gru(msg[nd].unsqueeze(0), hprev[nd].unsqueeze(0))[1][0]
+    close(hnew, z['lvl_hnew'], msg='hnew')
+    (hnew * torch.tensor(z['lvl_up'], device=dev)).sum().backward()
+    close(ns.grad, z['lvl_grad_node_state'], rtol=1e-3, atol=1e-4, msg='grad node_state')
+    close(hprev.grad, z['lvl_grad_hprev'], rtol=1e-3, atol=1e-4, msg='grad hprev')
+    for k, p in aggr.named_parameters():
+        ref = z['lvl_grad_aggr_' + k]
+        if p.grad is None:
+            assert float(np.abs(ref).max()) < 1e-5, k
+            continue
+        g = p.grad.cpu().numpy()
+        if k == 'attn_lin.weight':
+            g, ref = g[:, H:], ref[:, H:]
+        close(g, ref, rtol=1e-3, atol=1e-4, msg='grad aggr ' + k)
+    for k, p in gru.named_parameters():
+        close(p.grad, z['lvl_grad_gru_' + k], rtol=1e-3, atol=1e-4, msg='grad gru ' + k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,N,E', [(16, 300, 900), (32, 5000, 20000), (64, 777, 12000), (32, 64, 0)])
+def test_standalone_aggregator_on_hip_against_the_composed_form(H, N, E):
+    """Random multigraphs (repeated edges, nodes without in-edges, one node with thousands of sources) against the CPU form."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from deepgate.arch.tfmlp import TFMlpAggr
+    g = torch.Generator().manual_seed(H + N)
+    dev = torch.device('cuda:0')
+    ei = torch.stack([torch.randint(0, N, (E,), generator=g), torch.randint(N // 3, N, (E,), generator=g)])
+    if E:
+        ei[1, :E // 4] = N - 1                        # a heavy destination
+    x = torch.randn(N, 2 * H, generator=g)
+    up = torch.randn(N, H, generator=g)
+    torch.manual_seed(5)
+    ref = TFMlpAggr(2 * H, H)
+    with torch.no_grad():
+        ref.attn_lin.weight.mul_(4.0)                 # sharper softmax than the default init gives
+    hip = TFMlpAggr(2 * H, H)
+    hip.load_state_dict(ref.state_dict())
+    hip = hip.to(dev)
+    xr = x.clone().requires_grad_(True)
+    xh = x.to(dev).requires_grad_(True)
+    yr = ref(xr, ei)
+    yh = hip(xh, ei.to(dev))
+    close(yh, yr, rtol=2e-4, atol=2e-5, msg='messages')
+    (yr * up).sum().backward()
+    (yh * up.to(dev)).sum().backward()
+    close(xh.grad, xr.grad, rtol=1e-3, atol=1e-4, msg='grad x')
+    for (k, pr), (_, ph) in zip(ref.named_parameters(), hip.named_parameters()):
+        assert (pr.grad is None) == (ph.grad is None), k
+        if pr.grad is not None:
+            close(ph.grad, pr.grad, rtol=1e-3, atol=1e-4, msg='grad ' + k)
