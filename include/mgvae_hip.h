@@ -160,6 +160,24 @@ int mgv_func_sweep_bwd(int H, int64_t N, int T, int num_levels, const int32_t* l
                        const float* Wvc, const float* WvcT, const float* bvc, const float* bih, const float* bhh,
                        const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc, float* d_attn_u,
                        float* dWvc, float* dbvc, float* dbih, float* dbhh, void* stream);
+/* rounds r >= 2 on the fp32 kernels (dg_ae_model_aig.py:70 with num_rounds > 1): every updated gate's GRU starts from its state of
+ * the previous round.  Same contract as mgv_func_sweep_round_fwd_x3 / _bwd_x3 below: hf holds the previous round's rows on entry
+ * (updated rows are rewritten), gh[N][3H] = W_hh h_prev + b_hh of each node's own aggregator, h_prev[N][H], zero_bhh[T][3H] zeros;
+ * backward: d_gh[N][3H] and g_hprev[N][H] = dh * z (rows of updated nodes written; the caller zeroes both), ghs is ADDED to. */
+int mgv_func_sweep_round_fwd(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                             const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
+                             const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src, const float* hs,
+                             float* hf, const float* attn_u, const float* Wvc, const float* bvc, const float* bih,
+                             const float* zero_bhh, const float* gh, const float* h_prev, void* stream);
+int mgv_func_sweep_round_bwd(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                             const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
+                             const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src,
+                             const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_slot,
+                             const uint8_t* gslot, const float* hs, const float* hf, const float* attn_u,
+                             const float* Wvc, const float* WvcT, const float* bvc, const float* bih, const float* zero_bhh,
+                             const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc, float* d_attn_u,
+                             float* dWvc, float* dbvc, float* dbih, float* dbhh_unused, const float* gh, const float* h_prev,
+                             float* d_gh, float* g_hprev, void* stream);
 
 /* the sweep on bf16x3 split-precision MFMA (H in {32, 64}, T <= 6).  Differences from the fp32 entry points:
  * wpack_bf16[T][4][6H^2] = per slot {Wvc_hi, Wvc_lo, WvcT_hi, WvcT_lo} as bf16 in MFMA fragment order

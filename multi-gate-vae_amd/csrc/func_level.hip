@@ -37,6 +37,9 @@ struct LevelArgs {
     float* dzb;            // [N][2H] d(zbar) per updated node
     float* alpha; float* dsc;   // [E] per in-edge (in-CSR order)
     float* d_attn_u; float* dWvc; float* dbvc; float* dbih; float* dbhh;
+    // rounds >= 2 (dg_ae_model_aig.py:70-97 with num_rounds > 1; same contract as LevelX3Args): gh[node][3H] = W_hh h_prev + b_hh of
+    // the node's own aggregator (bhh = 0 here), hprev[node][H]; backward leaves d(gh) and d(h_prev) = dh * z.  NULL in round 1.
+    const float* gh; const float* hprev; float* dgh; float* ghprev;
 };
 
 template <int H, bool BWD = true>
@@ -136,7 +139,7 @@ __device__ __forceinline__ void level_gemm(const float* Wvc_g, const float* s_z,
     }
 }
 
-template <int H>
+template <int H, bool HID = false>
 __global__ __launch_bounds__(kThreads) void k_level_fwd(LevelArgs a) {
     using S = WaveSplit<H>;
     using M = LevelSmem<H, false>;
@@ -182,10 +185,15 @@ __global__ __launch_bounds__(kThreads) void k_level_fwd(LevelArgs a) {
             for (int e = 0; e < 4; ++e) {
                 const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
                 const float sa = s_sa[row];
-                const float rr = sigmoidf_(ar[i][j][e] + sa * s_bvc[col] + s_bih[col] + s_bhh[col]);
-                const float zz = sigmoidf_(az[i][j][e] + sa * s_bvc[H + col] + s_bih[H + col] + s_bhh[H + col]);
-                const float nn = tanhf_(an[i][j][e] + sa * s_bvc[2 * H + col] + s_bih[2 * H + col] + rr * s_bhh[2 * H + col]);
-                s_o[row * S::LD + col] = (1.0f - zz) * nn;        // h0 = 0
+                float gr = 0.f, gz = 0.f, gn = 0.f, hp = 0.f;
+                if constexpr (HID) {       // previous-round state: gh = W_hh h + b_hh per gate block, h' = (1 - z) n + z h
+                    const int64_t node = s_node[row];
+                    if (node >= 0) { const float* g_ = a.gh + node * 3 * H + col; gr = g_[0]; gz = g_[H]; gn = g_[2 * H]; hp = a.hprev[node * H + col]; }
+                }
+                const float rr = sigmoidf_(ar[i][j][e] + sa * s_bvc[col] + s_bih[col] + s_bhh[col] + gr);
+                const float zz = sigmoidf_(az[i][j][e] + sa * s_bvc[H + col] + s_bih[H + col] + s_bhh[H + col] + gz);
+                const float nn = tanhf_(an[i][j][e] + sa * s_bvc[2 * H + col] + s_bih[2 * H + col] + rr * (s_bhh[2 * H + col] + gn));
+                s_o[row * S::LD + col] = (1.0f - zz) * nn + zz * hp;        // round 1: h0 = 0
             }
         }
     __syncthreads();
@@ -218,7 +226,7 @@ __device__ __forceinline__ void colsum_lds(float v, float* dst) {
     if ((threadIdx.x & 63) < 16) atomicAdd(dst, v);
 }
 
-template <int H>
+template <int H, bool HID = false>
 __global__ __launch_bounds__(kThreads) void k_level_bwd(LevelArgs a) {
     using S = WaveSplit<H>;
     using S2 = WaveSplit<2 * H>;
@@ -284,13 +292,27 @@ __global__ __launch_bounds__(kThreads) void k_level_bwd(LevelArgs a) {
             for (int e = 0; e < 4; ++e) {
                 const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
                 const float sa = s_sa[row];
-                const float rr = sigmoidf_(ar[i][j][e] + sa * s_bvc[col] + s_bih[col] + s_bhh[col]);
-                const float zz = sigmoidf_(az[i][j][e] + sa * s_bvc[H + col] + s_bih[H + col] + s_bhh[H + col]);
-                const float nn = tanhf_(an[i][j][e] + sa * s_bvc[2 * H + col] + s_bih[2 * H + col] + rr * bhn);
+                float gr = 0.f, gz = 0.f, gn = 0.f, hp = 0.f;
+                int64_t node = -1;
+                if constexpr (HID) {
+                    node = s_node[row];
+                    if (node >= 0) { const float* g_ = a.gh + node * 3 * H + col; gr = g_[0]; gz = g_[H]; gn = g_[2 * H]; hp = a.hprev[node * H + col]; }
+                }
+                const float ghn = bhn + gn;
+                const float rr = sigmoidf_(ar[i][j][e] + sa * s_bvc[col] + s_bih[col] + s_bhh[col] + gr);
+                const float zz = sigmoidf_(az[i][j][e] + sa * s_bvc[H + col] + s_bih[H + col] + s_bhh[H + col] + gz);
+                const float nn = tanhf_(an[i][j][e] + sa * s_bvc[2 * H + col] + s_bih[2 * H + col] + rr * ghn);
                 const float dh = s_d[row * S::LD + col];
                 const float dan = dh * (1.0f - zz) * (1.0f - nn * nn);
-                const float daz = -dh * nn * zz * (1.0f - zz);
-                const float dar = dan * bhn * rr * (1.0f - rr);
+                const float daz = dh * (hp - nn) * zz * (1.0f - zz);
+                const float dar = dan * ghn * rr * (1.0f - rr);
+                if constexpr (HID) {
+                    if (node >= 0) {
+                        float* d_ = a.dgh + node * 3 * H + col;
+                        d_[0] = dar; d_[H] = daz; d_[2 * H] = dan * rr;       // d(gh): the caller's linear kernels carry it to W_hh, b_hh, h_prev
+                        a.ghprev[node * H + col] = dh * zz;                   // the direct path to the previous state
+                    }
+                }
                 ar[i][j][e] = dar; az[i][j][e] = daz; an[i][j][e] = dan;
                 b_r += dar; b_z += daz; b_n += dan; h_n += dan * rr;
                 v_r += sa * dar; v_z += sa * daz; v_n += sa * dan;
@@ -419,32 +441,39 @@ __global__ __launch_bounds__(kThreads) void k_level_pull_inactive(LevelArgs a) {
     }
 }
 
-template <int H>
-int launch_level(bool bwd, const LevelArgs& a, int ntiles, hipStream_t st) {
+template <int H, bool HID>
+int launch_level_v(bool bwd, const LevelArgs& a, int ntiles, hipStream_t st) {
     using M = LevelSmem<H>;
     const size_t shm = (bwd ? (size_t)M::bwd_floats : (size_t)LevelSmem<H, false>::fwd_floats) * sizeof(float);
     if (bwd) {
         static bool set_b = false;
-        if (!set_b) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_bwd<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_b = true; }
-        hipLaunchKernelGGL(k_level_bwd<H>, dim3(ntiles), dim3(kThreads), shm, st, a);
+        if (!set_b) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_bwd<H, HID>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_b = true; }
+        hipLaunchKernelGGL((k_level_bwd<H, HID>), dim3(ntiles), dim3(kThreads), shm, st, a);
     } else {
         static bool set_f = false;
-        if (!set_f) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_fwd<H>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_f = true; }
-        hipLaunchKernelGGL(k_level_fwd<H>, dim3(ntiles), dim3(kThreads), shm, st, a);
+        if (!set_f) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_level_fwd<H, HID>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set_f = true; }
+        hipLaunchKernelGGL((k_level_fwd<H, HID>), dim3(ntiles), dim3(kThreads), shm, st, a);
     }
     MGV_LAUNCH_RET();
+}
+
+template <int H>
+int launch_level(bool bwd, const LevelArgs& a, int ntiles, hipStream_t st) {
+    return a.gh ? launch_level_v<H, true>(bwd, a, ntiles, st) : launch_level_v<H, false>(bwd, a, ntiles, st);
 }
 
 }  // namespace mgv
 
 // Runs levels [1, L) forward.  level_tile_ptr is a HOST array of L+1 tile offsets.
-extern "C" int mgv_func_sweep_fwd(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+static int sweep_fwd_impl(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
                                   const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
                                   const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src, const float* hs,
                                   float* hf, const float* attn_u, const float* Wvc, const float* bvc, const float* bih,
-                                  const float* bhh, void* stream) {
+                                  const float* bhh, const float* gh, const float* h_prev, void* stream) {
     MGV_CHECK_ARG(N >= 0 && T >= 1 && num_levels >= 0 && level_tile_ptr_host && hs && hf && attn_u && Wvc && bvc && bih && bhh && in_ptr);
+    MGV_CHECK_ARG((gh == nullptr) == (h_prev == nullptr));
     mgv::LevelArgs a{};
+    a.gh = gh; a.hprev = h_prev;
     a.N = N; a.T = T; a.order = order; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot;
     a.in_ptr = in_ptr; a.in_src = in_src; a.hs = hs; a.hf = hf; a.attn_u = attn_u; a.Wvc = Wvc; a.bvc = bvc; a.bih = bih; a.bhh = bhh;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -465,18 +494,40 @@ extern "C" int mgv_func_sweep_fwd(int H, int64_t N, int T, int num_levels, const
     return MGV_OK;
 }
 
-extern "C" int mgv_func_sweep_bwd(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+extern "C" int mgv_func_sweep_fwd(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                                  const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
+                                  const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src, const float* hs,
+                                  float* hf, const float* attn_u, const float* Wvc, const float* bvc, const float* bih,
+                                  const float* bhh, void* stream) {
+    return sweep_fwd_impl(H, N, T, num_levels, level_tile_ptr_host, order, tile_start, tile_count, tile_slot, in_ptr, in_src, hs, hf, attn_u, Wvc,
+                          bvc, bih, bhh, nullptr, nullptr, stream);
+}
+
+extern "C" int mgv_func_sweep_round_fwd(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                                        const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
+                                        const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src, const float* hs,
+                                        float* hf, const float* attn_u, const float* Wvc, const float* bvc, const float* bih,
+                                        const float* zero_bhh, const float* gh, const float* h_prev, void* stream) {
+    MGV_CHECK_ARG(gh && h_prev);
+    return sweep_fwd_impl(H, N, T, num_levels, level_tile_ptr_host, order, tile_start, tile_count, tile_slot, in_ptr, in_src, hs, hf, attn_u, Wvc,
+                          bvc, bih, zero_bhh, gh, h_prev, stream);
+}
+
+static int sweep_bwd_impl(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
                                   const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
                                   const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src,
                                   const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_slot,
                                   const uint8_t* gslot, const float* hs, const float* hf, const float* attn_u,
                                   const float* Wvc, const float* WvcT, const float* bvc, const float* bih, const float* bhh,
                                   const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc, float* d_attn_u,
-                                  float* dWvc, float* dbvc, float* dbih, float* dbhh, void* stream) {
+                                  float* dWvc, float* dbvc, float* dbih, float* dbhh, const float* gh, const float* h_prev,
+                                  float* d_gh, float* g_hprev, void* stream) {
     MGV_CHECK_ARG(N >= 0 && T >= 1 && num_levels >= 0 && level_tile_ptr_host && hs && hf && attn_u && Wvc && WvcT && bvc && bih && bhh);
     MGV_CHECK_ARG(in_ptr && out_ptr && gslot && ghf && ghs && dzb && d_attn_u && dWvc && dbvc && dbih && dbhh);
+    MGV_CHECK_ARG(gh == nullptr ? (!h_prev && !d_gh && !g_hprev) : (h_prev && d_gh && g_hprev));
     if (N == 0) return MGV_OK;
     mgv::LevelArgs a{};
+    a.gh = gh; a.hprev = h_prev; a.dgh = d_gh; a.ghprev = g_hprev;
     a.N = N; a.T = T; a.order = order; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot;
     a.in_ptr = in_ptr; a.in_src = in_src; a.hs = hs; a.hf = const_cast<float*>(hf); a.attn_u = attn_u; a.Wvc = Wvc; a.bvc = bvc;
     a.bih = bih; a.bhh = bhh; a.WvcT = WvcT; a.out_ptr = out_ptr; a.out_dst = out_dst; a.out_slot = out_slot; a.gslot = gslot;
@@ -507,4 +558,32 @@ extern "C" int mgv_func_sweep_bwd(int H, int64_t N, int T, int num_levels, const
         default: return MGV_EUNSUPPORTED;
     }
     MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_func_sweep_bwd(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                                  const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
+                                  const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src,
+                                  const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_slot,
+                                  const uint8_t* gslot, const float* hs, const float* hf, const float* attn_u,
+                                  const float* Wvc, const float* WvcT, const float* bvc, const float* bih, const float* bhh,
+                                  const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc, float* d_attn_u,
+                                  float* dWvc, float* dbvc, float* dbih, float* dbhh, void* stream) {
+    return sweep_bwd_impl(H, N, T, num_levels, level_tile_ptr_host, order, tile_start, tile_count, tile_slot, in_ptr, in_src, out_ptr, out_dst,
+                          out_slot, gslot, hs, hf, attn_u, Wvc, WvcT, bvc, bih, bhh, ghf, ghs, dzb, alpha, dsc, d_attn_u, dWvc, dbvc, dbih, dbhh,
+                          nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int mgv_func_sweep_round_bwd(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
+                                        const int32_t* order, const int32_t* tile_start, const int32_t* tile_count,
+                                        const int32_t* tile_slot, const int32_t* in_ptr, const int32_t* in_src,
+                                        const int32_t* out_ptr, const int32_t* out_dst, const int32_t* out_slot,
+                                        const uint8_t* gslot, const float* hs, const float* hf, const float* attn_u,
+                                        const float* Wvc, const float* WvcT, const float* bvc, const float* bih, const float* zero_bhh,
+                                        const float* ghf, float* ghs, float* dzb, float* alpha, float* dsc, float* d_attn_u,
+                                        float* dWvc, float* dbvc, float* dbih, float* dbhh_unused, const float* gh, const float* h_prev,
+                                        float* d_gh, float* g_hprev, void* stream) {
+    MGV_CHECK_ARG(gh && h_prev && d_gh && g_hprev);
+    return sweep_bwd_impl(H, N, T, num_levels, level_tile_ptr_host, order, tile_start, tile_count, tile_slot, in_ptr, in_src, out_ptr, out_dst,
+                          out_slot, gslot, hs, hf, attn_u, Wvc, WvcT, bvc, bih, zero_bhh, ghf, ghs, dzb, alpha, dsc, d_attn_u, dWvc, dbvc, dbih,
+                          dbhh_unused, gh, h_prev, d_gh, g_hprev, stream);
 }

@@ -20,65 +20,6 @@ DEVICE_SAMPLER = os.environ.get('MGV_NEG_SAMPLER', 'device') != 'torch'
 MAX_LOGSTD = 10
 
 
-def _round_params(aggr, gru):
-    return [aggr.attn_lin.weight, aggr.msg_k.weight, aggr.msg_v.weight, aggr.msg_v.bias,
-            gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0]
-
-
-def _level_update(aggr, gru, xs, xf, seg, n, hprev):
-    """One (level, gate type) group: attention messages from the gathered source rows, GRU from the previous state."""
-    msg = aggr.attend(torch.cat([xs, xf], dim=1), seg, n)
-    return gru(msg.unsqueeze(0), hprev.unsqueeze(0))[1].squeeze(0)
-
-
-class ExtraRoundFn(torch.autograd.Function):
-    """Round r >= 2 of the functional sweep (dg_ae_model_aig.py:70-97): level by level, every gate's state is updated from its
-    sources' current states (already updated this round) and its own previous state.  Forward runs in place under no_grad;
-    backward walks the levels in reverse, recomputes each group with autograd on its gathered rows and pulls/accumulates
-    gradients with O(group) index operations (no N-sized temporaries per level)."""
-
-    @staticmethod
-    def forward(ctx, plan, mods, hs, hf_in, *params):
-        groups = plan.level_groups()
-        hf = hf_in.detach().clone()
-        hsd = hs.detach()
-        with torch.no_grad():
-            for nodes, slot, src, seg in groups:
-                aggr, gru = mods[slot]
-                hf[nodes] = _level_update(aggr, gru, hsd[src], hf[src], seg, nodes.numel(), hf_in.detach()[nodes])
-        ctx.plan, ctx.mods, ctx.n_params = plan, mods, len(params)
-        ctx.save_for_backward(hsd, hf_in.detach(), hf)
-        return hf
-
-    @staticmethod
-    def backward(ctx, g_out):
-        hs, hf_in, hf = (t.detach() for t in ctx.saved_tensors)     # the saved OUTPUT comes back attached to this very node
-        groups = ctx.plan.level_groups()
-        g_hf = g_out.detach().clone()
-        g_hs = torch.zeros_like(hs)
-        per = ctx.n_params // len(ctx.mods)
-        g_par = [None] * ctx.n_params
-        for nodes, slot, src, seg in reversed(groups):
-            aggr, gru = ctx.mods[slot]
-            par = _round_params(aggr, gru)
-            with torch.enable_grad():
-                xs = hs[src].requires_grad_(True)
-                xf = hf[src].requires_grad_(True)
-                hp = hf_in[nodes].requires_grad_(True)
-                out = _level_update(aggr, gru, xs, xf, seg, nodes.numel(), hp)
-                grads = torch.autograd.grad(out, [xs, xf, hp] + par, grad_outputs=g_hf[nodes], allow_unused=True)
-            # every consumer of these nodes' new states sits at a higher level and has been processed: the rows now carry the
-            # gradient with respect to their PREVIOUS states
-            g_hf[nodes] = grads[2]
-            g_hf.index_add_(0, src, grads[1])
-            g_hs.index_add_(0, src, grads[0])
-            for k, g in enumerate(grads[3:]):
-                if g is not None:
-                    i = slot * per + k
-                    g_par[i] = g if g_par[i] is None else g_par[i] + g
-        return (None, None, g_hs, g_hf) + tuple(g_par)
-
-
 class FunctionalModel(nn.Module):
     ENCODER_ATTR = 'struct_encoder'
     GATES = ()            # ((name, gate id), ...) in the order the reference creates aggr_*/update_* modules
@@ -132,15 +73,10 @@ class FunctionalModel(nn.Module):
         self._hs_pass = None
         hf = ops.FuncSweepFn.apply(plan, hs_in, *self._sweep_params())
         # further rounds (dg_ae_model_aig.py:70; the reference default and train.py use 1): every gate is updated again, its GRU
-        # starting from the gate's previous state.  On the HIP level kernels (ops.FuncSweepRoundFn) whenever the bf16x3 sweep serves
-        # this width; otherwise (exact-fp32 mode, H = 16, batches with high fan-out lists) the round composed from PyTorch operators.
+        # starting from the gate's previous state, on the same level kernels (ops.FuncSweepRoundFn)
         for _ in range(self.num_rounds - 1):
-            if ops.sweep_round_on_hip(plan, self.dim_hidden):
-                au, Wvc, bvc, bih, _ = self._sweep_params()
-                hf = ops.FuncSweepRoundFn.apply(plan, hs_in, hf, self._round_gh(plan, hf), au, Wvc, bvc, bih)
-            else:
-                mods = [(getattr(self, 'aggr_%s_func' % n), getattr(self, 'update_%s_func' % n)) for n, _ in self.GATES]
-                hf = ExtraRoundFn.apply(plan, mods, hs_in, hf, *[p for a, g in mods for p in _round_params(a, g)])
+            au, Wvc, bvc, bih, _ = self._sweep_params()
+            hf = ops.FuncSweepRoundFn.apply(plan, hs_in, hf, self._round_gh(plan, hf), au, Wvc, bvc, bih)
         return hs, hf
 
     def _round_gh(self, plan, hf):

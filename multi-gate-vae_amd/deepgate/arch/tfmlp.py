@@ -2,17 +2,10 @@
 in-edges, q from the destination, k/v from the sources.
 
 Inside a Model the module is a parameter container: `Model.forward` composes `attn_u`, `Wvc`, `bvc`
-from its weights and runs the levelised sweep kernel.  `composed()` is that composition."""
+from its weights and runs the levelised sweep kernel.  `composed()` is that composition; `forward()` (an edge-list
+call on its own) runs the attention-pooling kernels."""
 import torch
 import torch.nn as nn
-
-
-def segment_softmax(a, seg, n):
-    """torch_geometric.utils.softmax over segments `seg` (values 0..n-1): exp(a - max) / (sum + 1e-16)."""
-    m = torch.full((n,), float('-inf'), dtype=a.dtype, device=a.device).scatter_reduce(0, seg, a, 'amax', include_self=True)
-    e = torch.exp(a - m[seg])
-    s = torch.zeros(n, dtype=a.dtype, device=a.device).index_add(0, seg, e)
-    return e / (s[seg] + 1e-16)
 
 
 class TFMlpAggr(nn.Module):
@@ -42,26 +35,16 @@ class TFMlpAggr(nn.Module):
         w_ih = gru.weight_ih_l0
         return attn_u, w_ih @ self.msg_v.weight, w_ih @ self.msg_v.bias, gru.bias_ih_l0, gru.bias_hh_l0
 
-    def attend(self, x_src, seg, n):
-        """Messages of n destinations from gathered source rows: x_src[e] is the source row of edge e, seg[e] its
-        destination (0..n-1).  Same restatement as the sweep kernel: the q term is constant over a destination's softmax
-        segment and cancels, so the score is (Wk^T w_k).x_j (tfmlp.py:38-46)."""
-        out = self.msg_k.weight.shape[0]
-        u = self.attn_lin.weight[0, out:] @ self.msg_k.weight
-        alpha = segment_softmax(x_src @ u, seg, n)
-        v = torch.nn.functional.linear(x_src, self.msg_v.weight, self.msg_v.bias) * alpha.unsqueeze(1)
-        return torch.zeros(n, out, dtype=x_src.dtype, device=x_src.device).index_add(0, seg, v)
-
     def forward(self, x, edge_index, edge_attr=None, plan=None, **kwargs):
         """Stand-alone edge-list call (tfmlp.py:31-35): [N, out] messages, zero rows for nodes without in-edges.
-        On the device: attention pooling of the source rows (csrc/attn_pool.hip) followed by the value Linear,
-        W_v (sum_j alpha_j x_j) + b_v [deg > 0] = sum_j alpha_j (W_v x_j + b_v).  `plan` = a GraphPlan of edge_index saves
-        building the CSR.  On a CPU tensor (host tests) the same arithmetic composed from PyTorch operators."""
-        if not x.is_cuda:
-            src, dst = edge_index[0].long(), edge_index[1].long()
-            return self.attend(x.index_select(0, src), dst, x.shape[0])
+        Attention pooling of the source rows (csrc/attn_pool.hip: the q term is constant over a destination's softmax segment and
+        cancels, so the score is (Wk^T w_k).x_j, tfmlp.py:38-46) followed by the value Linear,
+        W_v (sum_j alpha_j x_j) + b_v [deg > 0] = sum_j alpha_j (W_v x_j + b_v).  `plan` = a GraphPlan of edge_index saves building
+        the CSR.  Device tensors only: there is no CPU implementation."""
         from .. import ops
         from ..graph_plan import GraphPlan
+        if not x.is_cuda:
+            raise ops._hip.HipLibraryError('TFMlpAggr.forward needs device tensors (got %s); there is no CPU implementation' % x.device)
         if plan is None:
             plan = GraphPlan(edge_index, x.shape[0])
         out = self.msg_k.weight.shape[0]

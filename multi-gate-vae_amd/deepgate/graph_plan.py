@@ -247,7 +247,6 @@ class GraphPlan:
     def _drop_level_caches(self):
         """Caches derived from gslot / level (and the tagged neighbour arrays): stale once the levels are set again, which
         `data.plan_of` does when a batch meets a model with another gate set."""
-        self._groups = None
         self.__dict__.pop('_heavy_seg', None)
         self.__dict__.pop('_tagged', None)
         self.__dict__.pop('_slot_nodes', None)
@@ -390,35 +389,3 @@ class GraphPlan:
             assert self.has_levels
             self._slot_nodes = [torch.nonzero(self.gslot == s_).reshape(-1) for s_ in range(self.num_slots)]
         return self._slot_nodes
-
-    def level_groups(self):
-        """[(nodes, slot, src, seg)] per (level, gate type) group in ascending level order, as int64 device tensors: the group's
-        nodes, the sources of their in-edges and each edge's position in `nodes`.  Only the multi-round compatibility path
-        uses it (built once per plan, one host copy of the tile tables)."""
-        if getattr(self, '_groups', None) is not None:
-            return self._groups
-        assert self.has_levels
-        ts, tc, tl = (t.cpu().tolist() for t in (self.tile_start, self.tile_count, self.tile_slot))
-        order = self.order.long()
-        in_ptr = self.in_ptr.long()
-        in_src = self.in_src.long()
-        groups = []
-        ltp = list(self.level_tile_ptr)
-        for lv in range(1, len(ltp) - 1):
-            t = ltp[lv]
-            while t < ltp[lv + 1]:
-                slot, start, end = tl[t], ts[t], ts[t] + tc[t]
-                t += 1
-                while t < ltp[lv + 1] and tl[t] == slot:
-                    end = ts[t] + tc[t]
-                    t += 1
-                nodes = order[start:end]
-                e0, e1 = in_ptr[nodes], in_ptr[nodes + 1]
-                deg = e1 - e0
-                seg = torch.repeat_interleave(torch.arange(nodes.numel(), device=nodes.device), deg)
-                first = torch.cumsum(deg, 0) - deg
-                eid = e0[seg] + (torch.arange(seg.numel(), device=nodes.device) - first[seg])
-                groups.append((nodes, slot, in_src[eid], seg))
-        self._groups = groups
-        return groups
-

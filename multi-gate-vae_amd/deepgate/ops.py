@@ -485,20 +485,18 @@ def _sweep_bwd_prep(plan, T, H, dev):
     return scratch, stp, hv, ha
 
 
-def sweep_round_on_hip(plan, H):
-    """Rounds >= 2 of the sweep run on the level kernels (mgv_func_sweep_round_*_x3) when the bf16x3 sweep serves this width and
-    the batch has no high fan-out list on the sweep's pull paths (those keep the PyTorch-composed round, _model_base.ExtraRoundFn)."""
-    if not (use_x3(H) and H in (32, 64) and os.environ.get('MGV_SWEEP_X3', '1') != '0' and plan.device.type == 'cuda'):
-        return False
-    return plan.heavy_segments(True, inactive_only=True) is None and plan.heavy_segments(True, active_by_level=True) is None
+def _sweep_x3(H):
+    """The bf16x3 level kernels serve this width (else the exact-fp32 ones: H = 16, MGV_PRECISION=f32, MGV_SWEEP_X3=0)."""
+    return use_x3(H) and os.environ.get('MGV_SWEEP_X3', '1') != '0'
 
 
 class FuncSweepRoundFn(torch.autograd.Function):
-    """Round r >= 2 of the functional sweep (dg_ae_model_aig.py:70-97 with num_rounds > 1) on the HIP level kernels:
-    hf_new = sweep(hs, hf_prev) where every updated gate's GRU starts from its previous state.  `gh` [N, 3H] = W_hh h_prev + b_hh of
-    each node's own aggregator, formed by the caller with ops.linear (so that autograd carries its gradient to W_hh, b_hh and
-    h_prev through the linear kernels); the level kernels add it to the gate pre-activations, mix z * h_prev into the new state and
-    leave d(gh) and dh * z on the way back."""
+    """Round r >= 2 of the functional sweep (dg_ae_model_aig.py:70-97 with num_rounds > 1) on the HIP level kernels (bf16x3 or
+    exact fp32, as round 1): hf_new = sweep(hs, hf_prev) where every updated gate's GRU starts from its previous state.
+    `gh` [N, 3H] = W_hh h_prev + b_hh of each node's own aggregator, formed by the caller with ops.linear (so that autograd carries
+    its gradient to W_hh, b_hh and h_prev through the linear kernels); the level kernels add it to the gate pre-activations, mix
+    z * h_prev into the new state and leave d(gh) and dh * z on the way back.  High fan-out lists take the same pre-passes as in
+    round 1 (GraphPlan.heavy_segments)."""
 
     @staticmethod
     def forward(ctx, plan, hs, hprev, gh, attn_u, Wvc, bvc, bih):
@@ -510,12 +508,17 @@ class FuncSweepRoundFn(torch.autograd.Function):
         T = par[0].shape[0]
         assert plan.has_levels and plan.num_slots == T and plan.N == N and ghd.shape == (N, 3 * H) and hp.shape == (N, H)
         ltp = (_hip.ctypes.c_int32 * len(plan.level_tile_ptr))(*plan.level_tile_ptr)
-        wpack = sweep_wpack(par[1])
+        wpack = sweep_wpack(par[1]) if _sweep_x3(H) else None
         zb = torch.zeros(T, 3 * H, dtype=F32, device=hsd.device)
         hf = hp.clone()                      # never-updated rows keep their state; every updated row is rewritten by its level
-        _hip.call('mgv_func_sweep_round_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.order_span),
-                  ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
-                  ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(zb), ptr(ghd), ptr(hp))
+        if wpack is not None:
+            _hip.call('mgv_func_sweep_round_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.order_span),
+                      ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
+                      ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(zb), ptr(ghd), ptr(hp))
+        else:
+            _hip.call('mgv_func_sweep_round_fwd', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.tile_start),
+                      ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
+                      ptr(par[0]), ptr(par[1]), ptr(par[2]), ptr(par[3]), ptr(zb), ptr(ghd), ptr(hp))
         ctx.plan, ctx.par, ctx.ltp, ctx.wpack, ctx.zb = plan, par, ltp, wpack, zb
         ctx.save_for_backward(hsd, hf, hp, ghd)
         return hf
@@ -528,21 +531,34 @@ class FuncSweepRoundFn(torch.autograd.Function):
         T = par[0].shape[0]
         dev = hs.device
         ghf = check(ghf.contiguous(), F32, 'ghf')
-        ghs = torch.empty(N, H, dtype=F32, device=dev)
         dzb = torch.empty(N, 2 * H, dtype=F32, device=dev)
         alpha = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
         dsc = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
         grads = [torch.zeros_like(t) for t in par] + [torch.zeros_like(ctx.zb)]      # the last one (dbhh) is not meaningful here
         d_gh = torch.zeros(N, 3 * H, dtype=F32, device=dev)          # rows of never-updated nodes stay zero
         g_hprev = torch.zeros(N, H, dtype=F32, device=dev)           # (their states are constants of round 1: no gradient to carry)
+        if ctx.wpack is None:
+            ghs = torch.zeros(N, H, dtype=F32, device=dev)           # the fp32 kernels add to it
+            WvcT = par[1].transpose(1, 2).contiguous()
+            _hip.call('mgv_func_sweep_round_bwd', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.tile_start),
+                      ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr),
+                      ptr(plan.out_dst), ptr(plan.out_slot), ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]), ptr(par[1]),
+                      ptr(WvcT), ptr(par[2]), ptr(par[3]), ptr(ctx.zb), ptr(ghf), ptr(ghs), ptr(dzb), ptr(alpha), ptr(dsc),
+                      *[ptr(g) for g in grads], ptr(ghd), ptr(hp), ptr(d_gh), ptr(g_hprev))
+            return (None, ghs, g_hprev, d_gh, grads[0], grads[1], grads[2], grads[3])
+        ghs = torch.empty(N, H, dtype=F32, device=dev)
         scratch, stp, hv, ha = _sweep_bwd_prep(plan, T, H, dev)
-        assert hv is None and ha[0] == 0, 'high fan-out lists take the composed round (sweep_round_on_hip)'
         _hip.call('mgv_func_sweep_round_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.order_span),
                   plan.n_active, ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.slot_tiles), stp,
                   ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr), ptr(plan.out_dst), ptr(plan.out_slot),
                   ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]), ptr(ctx.wpack), ptr(par[2]), ptr(par[3]), ptr(ctx.zb),
                   ptr(ghf), ptr(ghs), ptr(dzb), ptr(alpha), ptr(dsc), *[ptr(g) for g in grads], ptr(scratch),
-                  scratch.numel(), 0, *ha, ptr(ghd), ptr(hp), ptr(d_gh), ptr(g_hprev))
+                  scratch.numel(), plan.HEAVY_ROW if hv is not None else 0, *ha, ptr(ghd), ptr(hp), ptr(d_gh), ptr(g_hprev))
+        if hv is not None:
+            # primary inputs (never updated) that drive thousands of gates: their pull by whole workgroups, per list segment
+            pw = workspace(hv['S'] * H, dev)
+            _hip.call('mgv_sweep_pull_heavy', H, hv['K'], ptr(hv['nodes']), ptr(hv['node_seg_ptr']), hv['S'], ptr(hv['seg_e0']), ptr(hv['seg_e1']),
+                      ptr(plan.out_dst), ptr(plan.out_slot), ptr(plan.gslot), ptr(alpha), ptr(dsc), ptr(dzb), ptr(par[0]), ptr(pw), ptr(ghs))
         return (None, ghs, g_hprev, d_gh, grads[0], grads[1], grads[2], grads[3])
 
 
@@ -558,7 +574,7 @@ class FuncSweepFn(torch.autograd.Function):
         T = par[0].shape[0]
         assert plan.has_levels and plan.num_slots == T and plan.N == N
         ltp = (_hip.ctypes.c_int32 * len(plan.level_tile_ptr))(*plan.level_tile_ptr)
-        wpack = sweep_wpack(par[1]) if (use_x3(H) and os.environ.get('MGV_SWEEP_X3', '1') != '0') else None
+        wpack = sweep_wpack(par[1]) if _sweep_x3(H) else None
         if wpack is not None:
             hf = torch.empty(N, H, dtype=F32, device=hsd.device)          # every updated row is written by its level; the rest here
             _hip.call('mgv_sweep_zero_inactive', H, N, ptr(plan.gslot), ptr(hf))

@@ -232,24 +232,23 @@ def test_heavy_lists_and_segments_cover_the_long_lists_exactly(monkeypatch):
 
 def test_level_caches_are_dropped_when_levels_are_set_again():
     """data.plan_of re-runs set_levels when a batch meets a model with another gate set: the per-plan caches derived from
-    gslot / level (level groups, heavy segments, tagged neighbour arrays) must not survive that."""
+    gslot / level (per-slot node lists, heavy segments, tagged neighbour arrays) must not survive that."""
     from deepgate.graph_plan import GraphPlan
     ei = torch.tensor([[0, 1, 2, 2, 3], [2, 2, 3, 4, 4]])
     gate = torch.tensor([0., 0., 1., 2., 1.])
     lv = torch.tensor([0, 0, 1, 2, 3])
     p = GraphPlan(ei, 5)
     p.set_levels(gate, lv, [1, 2])
-    g1 = p.level_groups()
-    assert len(g1) == 3                                      # (level 1, AND), (level 2, NOT), (level 3, AND)
+    s1 = p.slot_nodes()
+    assert [s.tolist() for s in s1] == [[2, 4], [3]]         # AND nodes, NOT nodes
     cid = torch.tensor([0, 0, 1, 2, 1], dtype=torch.int32)
     t1 = p.tagged_idx(False, cid)
     assert p.tagged_idx(False, cid) is t1                    # same class-id tensor object: cached
     cid2 = cid.clone()
     assert p.tagged_idx(False, cid2) is not t1               # another tensor (even at a reused address): rebuilt
     p.set_levels(gate, lv, [1])                              # gate 2 no longer has an aggregator
-    assert p._groups is None and '_heavy_seg' not in p.__dict__ and '_tagged' not in p.__dict__
-    g2 = p.level_groups()
-    assert len(g2) == 2
+    assert '_slot_nodes' not in p.__dict__ and '_heavy_seg' not in p.__dict__ and '_tagged' not in p.__dict__
+    assert [s.tolist() for s in p.slot_nodes()] == [[2, 4]]
 
 
 def test_prefetcher_collates_like_collate_and_keeps_order():
