@@ -132,6 +132,22 @@ class GraphPlan:
             hit = cache[reverse] = (class_id, (idx | (class_id[idx.long()] << 24)).to(torch.int32).contiguous())
         return hit[1]
 
+    def warm(self, xcls=None):
+        """Build, on the CURRENT stream, the per-batch caches a train step would otherwise build lazily inside the step (each with a
+        host read-back): the first-stage (degree, class) table and the tagged lists of the half round after it, the heavy-row lists
+        and their segments.  The batch prefetcher calls this on its worker's stream, beside the previous step."""
+        for rev in (False, True):
+            self.heavy(rev)
+            self.heavy_segments(rev)
+        if self.has_levels:
+            self.heavy_segments(True, inactive_only=True)
+            self.heavy_segments(True, active_by_level=True)
+        if xcls is not None and self.N > 0:
+            first = self.first_stage_classes(xcls)
+            if first is not None and first[1] <= 256 and self.N < (1 << 24):
+                self.tagged_idx(True, first[0])
+        return self
+
     HEAVY_ROW = 64      # csrc/struct_stage_x3_common.h: kHeavyRow
 
     def heavy(self, reverse):

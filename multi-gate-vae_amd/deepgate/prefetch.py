@@ -68,6 +68,28 @@ def collate_into(graphs, staging, keys=None):
     return out, off
 
 
+def _record_all(v, stream, seen):
+    """record_stream on every device tensor reachable from `v` (dicts, lists, tuples, objects with a __dict__: the batch, its plan
+    and the plan's caches)."""
+    if torch.is_tensor(v):
+        if v.is_cuda:
+            v.record_stream(stream)
+        return
+    if id(v) in seen or isinstance(v, (str, bytes, int, float, bool, type(None), np.ndarray)):
+        return
+    seen.add(id(v))
+    if isinstance(v, dict):
+        for u in v.values():
+            _record_all(u, stream, seen)
+    elif isinstance(v, (list, tuple)):
+        if len(v) > 4096:               # host-side index tables (lists of ints)
+            return
+        for u in v:
+            _record_all(u, stream, seen)
+    elif hasattr(v, '__dict__'):
+        _record_all(v.__dict__, stream, seen)
+
+
 class BatchPrefetcher:
     """Iterate device-resident `CircuitBatch` objects over `chunks` (an iterable of lists of per-graph array dicts).
 
@@ -128,7 +150,11 @@ class BatchPrefetcher:
             st.event = copied
             self._free.put(st)
             if self.gate_ids is not None:
-                plan_of(b, self.gate_ids)        # its few host read-backs wait on THIS stream only
+                plan = plan_of(b, self.gate_ids)        # its few host read-backs wait on THIS stream only
+                plan.warm(plan.xcls)                    # ... and those of the caches the step would build lazily
+                if getattr(b, 'tt_pair_index', None) is not None and b.tt_pair_index.shape[1] >= 2:
+                    from . import ops
+                    b._mgv_pair_lists = ops.pair_lists(b.tt_pair_index, b.x.shape[0])
             ready = torch.cuda.Event()
             ready.record(stream)
         return b, ready
@@ -151,16 +177,7 @@ class BatchPrefetcher:
                     cur = torch.cuda.current_stream(self.device)
                     cur.wait_event(ready)
                     # the tensors were allocated on the worker's stream: tell the allocator that this stream uses them too
-                    for obj in (b, getattr(b, '_mgv_plan', None)):
-                        if obj is None:
-                            continue
-                        for v in obj.__dict__.values():
-                            if torch.is_tensor(v) and v.is_cuda:
-                                v.record_stream(cur)
-                            elif isinstance(v, (tuple, list)):
-                                for u in v:
-                                    if torch.is_tensor(u) and u.is_cuda:
-                                        u.record_stream(cur)
+                    _record_all(b.__dict__, cur, set())
                 yield b
         finally:
             for f in pending:
