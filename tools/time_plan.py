@@ -16,3 +16,8 @@ for rep in range(2):
     xcls = batch.x[:, 1].to(torch.uint8).contiguous()
     _, t3 = T(lambda: p.first_stage_classes(xcls))
     print('rep %d: CSRs %.1f ms, levels/tiles %.1f ms, class pairs %.1f ms' % (rep, t1, t2, t3))
+    from deepgate import ops
+    _, t4 = T(lambda: p.warm(xcls))
+    _, t5 = T(lambda: ops.pair_lists(batch.tt_pair_index, batch.x.shape[0]))
+    print('        warm (tagged lists, heavy rows) %.1f ms, pair lists %.1f ms' % (t4, t5))
+    p._stage1 = None; p.__dict__.pop('_tagged', None); p.__dict__.pop('_heavy', None); p.__dict__.pop('_heavy_seg', None)
