@@ -72,6 +72,16 @@ struct B2Args {
     float* slab;        // [gridDim][B2::SLAB]
 };
 
+// The kernel's arguments, re-read from the kernarg segment (scalar loads) behind an opaque copy of its address.  Used at the head of
+// every phase of the tile loop: the ~20 pointers and sizes the loop touches then live in scalar registers for one phase each instead
+// of for the whole kernel, where half of them were spilled to vector-register lanes and came back through v_readlane in the vector
+// pipe (54 spilled SGPRs, ~110 v_readlane / v_writelane per tile and wave).
+__device__ __forceinline__ const StageX3Args& kargs_now() {
+    const B2Args __attribute__((address_space(4)))* p = (const B2Args __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return ((const B2Args*)p)->s;
+}
+
 __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args) {
     const StageX3Args& a = args.s;
     constexpr int H = B2::H, LDP = B2::LDP, LDF = B2::LDF, BLK = 3 * H * H, PE = kTileRows * B2::LDP;   // PE: elements of one plane
@@ -104,6 +114,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
     (void)lane; (void)r; (void)q; (void)grp; (void)lr; (void)c0;
     const bool has_ln = a.lnw != nullptr;
     const bool need_dgrad = a.g_direct_out != nullptr;
+    const float ln_eps = a.eps;
     const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
 
     // Weight fragments (fragment-order pack: block, (row tile, k-step) of 512 elements, lane l at 8 l) are re-read from L2
@@ -160,6 +171,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
         STAMP_BEGIN;
         // ---- P0. row phase: gather, sum, split into the operand planes
         {
+            const StageX3Args& a = kargs_now();
             LANE_IDS
             float4 acc[2], own[2], dy[2];
             float deg[2];
@@ -193,8 +205,11 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
         __syncthreads();                                    // (1) planes, dY, deg/cls, next tile's pointers
         STAMP(1);
         // next tile's indices: requested now, parked in LDS before barrier (6)
-        idx_prefetch<kThreadsX3>(a, idx_lds(idx_base, b ^ 1).ptr, ri);
-        rp = ptr_prefetch(a, seq.at(it + 2), ntiles);
+        {
+            const StageX3Args& a = kargs_now();
+            idx_prefetch<kThreadsX3>(a, idx_lds(idx_base, b ^ 1).ptr, ri);
+            rp = ptr_prefetch(a, seq.at(it + 2), ntiles);
+        }
         tile_dmax(idx_lds(idx_base, b ^ 1).ptr, idx_lds(idx_base, b ^ 1).dmax());
         // ---- P1. pre-activations of this wave's matrix, transposed: lane (r, q) <- node 16 i + r, columns c0..c0+3
         f32x4 oa[3][2];                                     // own row tiles 2m, 2m+1: [gate][il]
@@ -234,7 +249,9 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
         //      for the next ~7,000 cycles, so nothing queues behind them on the in-order vmcnt.  The next row phase then gathers from
         //      the XCD's L2 instead of the fabric.  The loaded words only feed a comparison that never holds.
         unsigned pf0 = 0, pf1 = 0;
-        if (a.prefetch && seq.at(it + 1) < ntiles) {
+        if (seq.at(it + 1) < ntiles) {
+          const StageX3Args& a = kargs_now();
+          if (a.prefetch) {
             const int64_t nb = seq.at(it + 1) * kTileRows;
             const int* n_ptr = idx_lds(idx_base, b ^ 1).ptr;
             const int* n_idx = idx_lds(idx_base, b ^ 1).idx;
@@ -260,6 +277,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                 const int t = tid - 256;
                 if (t < ne2 && a.hshift == 0) pf0 = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)n_idx[t >> 1] * (H * 4) + 128u * (t & 1), 0, 0);
             }
+          }
         }
         // ---- P2. GRU forward values of row tiles 2m, 2m+1 and LayerNorm partials over this wave's 16 columns.  Written on 4-vectors
         //      (two packed fp32 operations each); the r and z gates only need Wc.agg + Whh.h, so the partner's half and this wave's
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                 const float mean = (p0[0] + p1[0] + p2[0] + p3[0]) * 0.25f;
                 const float e0 = p0[0] - mean, e1 = p1[0] - mean, e2 = p2[0] - mean, e3 = p3[0] - mean;
                 const float var = (p0[1] + p1[1] + p2[1] + p3[1] + 16.0f * (e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3)) * (1.0f / H);
-                const float rstd = rsqrtf(var + a.eps);
+                const float rstd = rsqrtf(var + ln_eps);
                 const float c1 = (p0[2] + p1[2] + p2[2] + p3[2]) * (1.0f / H);
                 const float c2 = (p0[3] + p1[3] + p2[3] + p3[3] + e0 * p0[2] + e1 * p1[2] + e2 * p2[2] + e3 * p3[2]) * rstd * (1.0f / H);
                 const float4 gm = ld4(sv.lnw + c0);
@@ -397,6 +415,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
         //      weight-gradient MFMAs that cover the latency (12 KB per wave and tile; 24 VGPRs at a time)
         f32x4 dgo[4];
         {
+            const StageX3Args& a = kargs_now();
             LANE_IDS
             const __bf16* x_hi = m ? hin_hi : agg_hi;
             const __bf16* x_lo = m ? hin_lo : agg_lo;
