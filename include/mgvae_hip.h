@@ -134,6 +134,14 @@ int mgv_gather_sum(int H, int64_t N, const float* h, const int32_t* nbr_ptr, con
  * (gy_direct[i] + sum_{j in nbr(i)} gy_agg[j]) (gy_agg may be NULL); C * H * 20 <= 160 KiB.  pull_sum is deterministic for
  * C <= 8: per-workgroup rows in `workspace` (>= mgv_class_pull_sum_ws_floats(H, N, C) floats), added in a fixed order. */
 int mgv_class_expand(int H, int64_t N, const float* table, const int32_t* class_id, float* out, void* stream);
+/* Segmented row sums in list order (one lane group per segment, no atomics): out[s][H] = sum over m in [seg_ptr[s], seg_ptr[s+1]) of
+ * v(item(m)), item(m) = items ? items[m] : m, v(i) = direct[i] + (agg ? sum of agg[nbr_idx[e]] over i's nbr list : 0).  The per-class
+ * sums of an incoming gradient for the quotient stages of the structural encoder (rows that are identical by construction are
+ * computed once: digae_layer.py:260 starts every node from ones, so early half rounds have few distinct rows): level 1 sums runs of
+ * <= 64 class members with the stage backward's neighbour pull fused, the next levels sum the partial rows. */
+int mgv_seg_sum(int H, int64_t n_seg, const int32_t* seg_ptr, const int32_t* items, const float* direct, const float* agg,
+                const int32_t* nbr_ptr, const int32_t* nbr_idx, float* out, void* stream);
+
 int mgv_class_pull_sum_ws_floats(int H, int64_t N, int C);
 int mgv_class_pull_sum(int H, int64_t N, const float* gy_direct, const float* gy_agg, const int32_t* nbr_ptr,
                        const int32_t* nbr_idx, const int32_t* class_id, int C, float* out, float* workspace,

@@ -253,6 +253,55 @@ __global__ __launch_bounds__(kThreads) void k_class_pull_sum(int64_t N, const fl
     }
 }
 
+// Segmented row sums, one lane group per segment, members added in list order (deterministic):
+//     out[s] = sum over m in [seg_ptr[s], seg_ptr[s+1]) of v(item(m)),   item(m) = items ? items[m] : m,
+//     v(i) = direct[i] + (agg ? sum over e in [nbr_ptr[i], nbr_ptr[i+1]) of agg[nbr_idx[e]] : 0).
+// The per-class sums of an incoming gradient (quotient stages of the structural encoder, ops.StructEncoderFn): level 1 sums runs
+// of <= 64 class members (with the neighbour pull of the stage's backward fused), further levels sum the partial rows; every
+// level's segments are cut class by class on the host side (GraphPlan.class_sum_levels), so no float atomics and no order left
+// to chance.  U members' loads are in flight together; the additions keep list order.
+template <int H>
+__global__ __launch_bounds__(kThreads) void k_seg_sum(int64_t n_seg, const int32_t* seg_ptr, const int32_t* items, const float* direct,
+                                                     const float* agg, const int32_t* ptr, const int32_t* idx, float* out) {
+    constexpr int LPR = H / 4, U = 4, D = 2;
+    const int lr = threadIdx.x % LPR;
+    const int64_t stride = (int64_t)gridDim.x * (kThreads / LPR);
+    for (int64_t s = (int64_t)blockIdx.x * (kThreads / LPR) + threadIdx.x / LPR; s < n_seg; s += stride) {
+        const int m0 = seg_ptr[s], m1 = seg_ptr[s + 1];
+        float4 acc = zero4();
+        for (int mb = m0; mb < m1; mb += U) {
+            int64_t row[U];
+            int e0[U], e1[U];
+            f32x4 own[U], nb[U][D];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                row[u] = -1; e0[u] = e1[u] = 0;
+                if (mb + u < m1) {
+                    row[u] = items ? (int64_t)items[mb + u] : (int64_t)(mb + u);
+                    own[u] = *reinterpret_cast<const f32x4*>(direct + row[u] * H + 4 * lr);
+                    if (agg) { e0[u] = ptr[row[u]]; e1[u] = ptr[row[u] + 1]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < D; ++k)
+                    if (e0[u] + k < e1[u]) nb[u][k] = *reinterpret_cast<const f32x4*>(agg + (int64_t)idx[e0[u] + k] * H + 4 * lr);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (row[u] < 0) continue;
+                float4 v = make_float4(own[u][0], own[u][1], own[u][2], own[u][3]);
+#pragma unroll
+                for (int k = 0; k < D; ++k)
+                    if (e0[u] + k < e1[u]) v = add4(v, make_float4(nb[u][k][0], nb[u][k][1], nb[u][k][2], nb[u][k][3]));
+                for (int e = e0[u] + D; e < e1[u]; ++e) v = add4(v, ld4(agg + (int64_t)idx[e] * H + 4 * lr));
+                acc = add4(acc, v);
+            }
+        }
+        st4(out + s * H + 4 * lr, acc);
+    }
+}
+
 template <int M>
 int launch_linear_fwd(const LinArgs& a, hipStream_t st) {
     const int K = a.K1 + a.K2;
@@ -323,6 +372,23 @@ extern "C" int mgv_gather_sum(int H, int64_t N, const float* h, const int32_t* n
         case 32: hipLaunchKernelGGL(mgv::k_gather_sum<32>, dim3(grid), dim3(mgv::kThreads), 0, st, N, h, nbr_ptr, nbr_idx, agg, deg); break;
         case 64: hipLaunchKernelGGL(mgv::k_gather_sum<64>, dim3(grid), dim3(mgv::kThreads), 0, st, N, h, nbr_ptr, nbr_idx, agg, deg); break;
         case 128: hipLaunchKernelGGL(mgv::k_gather_sum<128>, dim3(grid), dim3(mgv::kThreads), 0, st, N, h, nbr_ptr, nbr_idx, agg, deg); break;
+        default: return MGV_EUNSUPPORTED;
+    }
+    MGV_LAUNCH_RET();
+}
+
+extern "C" int mgv_seg_sum(int H, int64_t n_seg, const int32_t* seg_ptr, const int32_t* items, const float* direct, const float* agg,
+                           const int32_t* nbr_ptr, const int32_t* nbr_idx, float* out, void* stream) {
+    MGV_CHECK_ARG(n_seg >= 0 && seg_ptr && direct && out && (!agg || (nbr_ptr && nbr_idx)));
+    if (n_seg == 0) return MGV_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t rows_per_block = mgv::kThreads / (H / 4);
+    const int grid = mgv::grid_for((n_seg + rows_per_block - 1) / rows_per_block, 16);
+    switch (H) {
+        case 16: hipLaunchKernelGGL(mgv::k_seg_sum<16>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out); break;
+        case 32: hipLaunchKernelGGL(mgv::k_seg_sum<32>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out); break;
+        case 64: hipLaunchKernelGGL(mgv::k_seg_sum<64>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out); break;
+        case 128: hipLaunchKernelGGL(mgv::k_seg_sum<128>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out); break;
         default: return MGV_EUNSUPPORTED;
     }
     MGV_LAUNCH_RET();

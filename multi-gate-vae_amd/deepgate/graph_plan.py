@@ -132,7 +132,7 @@ class GraphPlan:
             hit = cache[reverse] = (class_id, (idx | (class_id[idx.long()] << 24)).to(torch.int32).contiguous())
         return hit[1]
 
-    def warm(self, xcls=None):
+    def warm(self, xcls=None, quotient_stages=0):
         """Build, on the CURRENT stream, the per-batch caches a train step would otherwise build lazily inside the step (each with a
         host read-back): the first-stage (degree, class) table and the tagged lists of the half round after it, the heavy-row lists
         and their segments.  The batch prefetcher calls this on its worker's stream, beside the previous step."""
@@ -142,6 +142,8 @@ class GraphPlan:
         if self.has_levels:
             self.heavy_segments(True, inactive_only=True)
             self.heavy_segments(True, active_by_level=True)
+        if xcls is not None and self.N > 0 and quotient_stages:
+            self.quotient(xcls, quotient_stages)
         if xcls is not None and self.N > 0:
             first = self.first_stage_classes(xcls)
             if first is not None and first[1] <= 256 and self.N < (1 << 24):
@@ -235,6 +237,106 @@ class GraphPlan:
                    (uniq % 256).to(torch.uint8).contiguous())
         self._stage1 = (key, out)
         return out
+
+    QUOTIENT_FRACTION = 4      # a half round runs on distinct rows only while they are at most N / 4
+
+    def quotient(self, xcls, max_stages):
+        """Quotient stages of the structural encoder.  Every node starts from the same state (ones, digae_layer.py:260), so after
+        half round t a node's row depends only on its colour: (feature class, colour after t-1, multiset of its neighbours' colours
+        after t-1) — colour refinement over the alternating in- / out-CSR.  While the colours are few (early half rounds of any
+        netlist: three gate types, bounded fan-in), the half round is computed on ONE row per colour.  Returns a list of stages
+        t = 1, 2, ... (possibly empty), each a dict:
+            C        colours after the stage;  cid [N] int32 colour of every node;  rev  the stage gathers over the out-CSR
+            ptr [C+1], idx int32: a representative's neighbour list, entries = C + (colour after t-1) — rows of the stacked input
+                     [own rows (C) | table of stage t-1 (C_prev)] the stage kernel reads;  own [C] int64: colour after t-1
+            xcls [C] uint8, heavy: (count, rows with more than HEAVY_ROW neighbours)
+            own_rows/own_levels, ent_rows/ent_levels: per colour of stage t-1 the representatives that own it / whose lists name it,
+                     as segment tables of mgv_seg_sum (backward)
+        and the last stage also `sum_levels` (class_sum_levels) for the per-colour sums of the per-node gradient.
+        Neighbour multisets are compared through two independent 64-bit sums of random per-colour values (a colour pair
+        collides with probability 2^-128); the 64-bit key they are folded into is checked member by member against each
+        colour's representative, refinement stops at the first disagreement.  Cached per xcls tensor."""
+        key = (xcls.data_ptr(), int(xcls.numel()), int(max_stages))
+        hit = getattr(self, '_quotient', None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        N, dev = self.N, self.device
+        stages = []
+        if N > 0 and self.E > 0:
+            i64 = dict(dtype=torch.int64, device=dev)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(0x5EED5)
+            xc = xcls.long()
+            prev, Cp = torch.zeros(N, **i64), 1
+            node = torch.arange(N, **i64)
+            for t_ in range(1, max_stages + 1):
+                rev = t_ % 2 == 0
+                p, idx = self.csr(rev)
+                pl, il = p.long(), idx.long()
+                deg = pl[1:] - pl[:-1]
+                owner = torch.repeat_interleave(node, deg)
+                f = torch.randint(1, 1 << 62, (3, Cp + 1), generator=gen, **i64)
+                pn = prev[il]
+                h1 = torch.zeros(N, **i64).index_add_(0, owner, f[0][pn])
+                h2 = torch.zeros(N, **i64).index_add_(0, owner, f[1][pn])
+                mix = h1 * 0x1E3779B97F4A7C15 + h2 + f[2][prev] + xc * 0x632BE59BD9B4E019 + deg * 0x2545F4914F6CDD1D
+                uniq, inv = torch.unique(mix, return_inverse=True)
+                C = int(uniq.numel())
+                if C * self.QUOTIENT_FRACTION > N:
+                    break
+                rep = torch.full((C,), N, **i64).scatter_reduce_(0, inv, node, 'amin')
+                ri = rep[inv]
+                same = (xc == xc[ri]) & (prev == prev[ri]) & (h1 == h1[ri]) & (h2 == h2[ri]) & (deg == deg[ri])
+                if not bool(same.all()):
+                    break
+                dr = deg[rep]
+                rptr = torch.zeros(C + 1, **i64)
+                rptr[1:] = torch.cumsum(dr, 0)
+                n_ent = int(rptr[-1].item())
+                row = torch.repeat_interleave(torch.arange(C, **i64), dr)
+                k = torch.arange(n_ent, **i64) - rptr[row]
+                ent = prev[il[pl[rep][row] + k]] if n_ent else torch.zeros(0, **i64)
+                own = prev[rep]
+                heavy = torch.nonzero(dr > self.HEAVY_ROW).reshape(-1).to(torch.int32)
+
+                # per colour of stage t-1: the representatives that own it / the list entries that name it, as segment tables of
+                # mgv_seg_sum (a colour like "AND gate" is named by thousands of entries: balanced, and summed in a fixed order)
+                own_o, own_levels = self.class_sum_levels(own, Cp)
+                ent_o, ent_levels = self.class_sum_levels(ent, Cp)
+                stages.append(dict(C=C, cid=inv.to(torch.int32).contiguous(), rev=rev, ptr=rptr.to(torch.int32).contiguous(),
+                                   idx=(ent + C).to(torch.int32).contiguous() if n_ent else torch.zeros(1, dtype=torch.int32, device=dev),
+                                   own=own, xcls=xcls[rep].contiguous(), heavy=(int(heavy.numel()), heavy.contiguous()),
+                                   own_rows=own_o, own_levels=own_levels,
+                                   ent_rows=row[ent_o.long()].to(torch.int32).contiguous() if n_ent else torch.zeros(1, dtype=torch.int32, device=dev),
+                                   ent_levels=ent_levels))
+                prev, Cp = inv, C
+            if stages:
+                stages[-1]['sum_levels'] = self.class_sum_levels(stages[-1]['cid'], stages[-1]['C'])
+        self._quotient = (key, stages)
+        return stages
+
+    def class_sum_levels(self, cid, C, seg=64):
+        """Segment tables of mgv_seg_sum for per-colour row sums: (order [N] int32 = nodes sorted by colour, [(n_seg, seg_ptr)] per
+        level).  Level 1 cuts every colour's run of members into segments of <= seg, level l+1 does the same with level l's
+        partial rows, until every colour is one segment; the last level's rows are the colours in order."""
+        dev = self.device
+        i64 = dict(dtype=torch.int64, device=dev)
+        order = torch.sort(cid.long(), stable=True).indices.to(torch.int32).contiguous()
+        counts = torch.bincount(cid.long(), minlength=C)
+        levels = []
+        while True:
+            nseg = torch.clamp((counts + seg - 1) // seg, min=1)         # (a colour nobody carries still gets its zero row)
+            total = int(nseg.sum().item())
+            cls = torch.repeat_interleave(torch.arange(C, **i64), nseg)
+            first = torch.cumsum(nseg, 0) - nseg
+            start = torch.cumsum(counts, 0) - counts
+            sp = torch.empty(total + 1, **i64)
+            sp[:total] = start[cls] + seg * (torch.arange(total, **i64) - first[cls])
+            sp[total] = counts.sum()
+            levels.append((total, sp.to(torch.int32).contiguous()))
+            if total == C:
+                return order, levels
+            counts = nseg
 
     def _first_stage_classes_hip(self, xcls, max_classes):
         from . import _hip

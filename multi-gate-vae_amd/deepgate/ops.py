@@ -97,9 +97,12 @@ def _heavy_args(heavy, H, device):
     return n, ptr(nodes), ptr(hw)
 
 
-def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, out=None, wpack=None, heavy=None, table_own=None):
-    """`table_own` (int32 [N]): table mode — h_in is the (degree, class) table, nbr_idx entries are tagged (GraphPlan.tagged_idx)."""
+def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, out=None, wpack=None, heavy=None, table_own=None, n_rows=None):
+    """`table_own` (int32 [N]): table mode — h_in is the (degree, class) table, nbr_idx entries are tagged (GraphPlan.tagged_idx).
+    `n_rows`: only the first n_rows rows of h_in are stage rows, the rest are rows their neighbour lists point at (quotient stages)."""
     N, H = h_in.shape
+    if n_rows is not None:
+        N = int(n_rows)
     if table_own is not None:
         N = table_own.numel()
     check(h_in, F32, 'h_in'); check(nbr_ptr, I32, 'nbr_ptr'); check(nbr_idx, I32, 'nbr_idx'); check(xcls, U8, 'xcls')
@@ -124,6 +127,7 @@ def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
 # slab-reduced deterministic parameter gradients); the first kernel (struct_stage_x3.hip) serves H = 32 only (tools/bench_stage.py
 # still times both through the C ABI).
 TABLE_MODE = os.environ.get('MGV_TABLE_MODE', '1') != '0'     # half round 2 of an encoder reads the (degree, class) table directly
+QUOTIENT = os.environ.get('MGV_QUOTIENT', '1') != '0'         # early half rounds on one row per colour (GraphPlan.quotient)
 _WS = {}
 
 
@@ -156,9 +160,11 @@ def _stage_ws(H, N, device):
 
 
 def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, gy_direct, gy_agg,
-                     grads, need_input_grad=True, wpack=None, heavy=None, table_own=None):
+                     grads, need_input_grad=True, wpack=None, heavy=None, table_own=None, n_rows=None):
     """`grads` = dict of fp32 accumulators (dWc, dbc, dWhh, dbhh, dxtab, dln_w, dln_b), added to."""
     N, H = h_in.shape
+    if n_rows is not None:
+        N = int(n_rows)
     if table_own is not None:
         N = table_own.numel()
     check(gy_direct, F32, 'gy_direct'); check(gy_agg, F32, 'gy_agg')
@@ -175,8 +181,8 @@ def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
         return g_direct, g_agg
     assert table_own is None, 'table mode needs the H = 64 bf16x3 backward'
     if use_x3(H):
-        g_direct = torch.empty_like(h_in) if need_input_grad else None
-        g_agg = torch.empty_like(h_in) if need_input_grad else None
+        g_direct = torch.empty(N, H, dtype=F32, device=h_in.device) if need_input_grad else None
+        g_agg = torch.empty(N, H, dtype=F32, device=h_in.device) if need_input_grad else None
         wpack = stage_wpack(Wc, Whh) if wpack is None else wpack
         _hip.call('mgv_struct_stage_bwd_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
                   xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(gy_direct),
@@ -185,14 +191,28 @@ def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
         return g_direct, g_agg
     WcT = Wc.t().contiguous()
     WhhT = Whh.t().contiguous()
-    g_direct = torch.empty_like(h_in) if need_input_grad else None
-    g_agg = torch.empty_like(h_in) if need_input_grad else None
+    g_direct = torch.empty(N, H, dtype=F32, device=h_in.device) if need_input_grad else None
+    g_agg = torch.empty(N, H, dtype=F32, device=h_in.device) if need_input_grad else None
     _hip.call('mgv_struct_stage_bwd', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
               xtab.shape[0], ptr(Wc), ptr(WcT), ptr(bc), ptr(Whh), ptr(WhhT), ptr(bhh), ptr(ln_w), ptr(ln_b),
               LN_EPS, ptr(gy_direct), ptr(gy_agg), ptr(g_direct), ptr(g_agg), ptr(grads['dWc']), ptr(grads['dbc']),
               ptr(grads['dWhh']), ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')),
               ptr(grads.get('dln_b')))
     return g_direct, g_agg
+
+
+def _seg_sums(H, levels, items, direct, agg=None, nbr_ptr=None, nbr_idx=None):
+    """Per-group row sums through the segment tables of GraphPlan.class_sum_levels: level 1 reads rows `items` of `direct` (+ the
+    neighbour pull of `agg`), every further level the partial rows of the one before; the last level's rows are the groups."""
+    rows = None
+    for li, (n_seg, seg_ptr) in enumerate(levels):
+        out = torch.empty(n_seg, H, dtype=F32, device=direct.device)
+        if li == 0:
+            _hip.call('mgv_seg_sum', H, n_seg, ptr(seg_ptr), ptr(items), ptr(direct), ptr(agg), ptr(nbr_ptr), ptr(nbr_idx), ptr(out))
+        else:
+            _hip.call('mgv_seg_sum', H, n_seg, ptr(seg_ptr), None, ptr(rows), None, None, None, ptr(out))
+        rows = out
+    return rows
 
 
 class StructEncoderFn(torch.autograd.Function):
@@ -215,6 +235,10 @@ class StructEncoderFn(torch.autograd.Function):
         packs = (stage_wpack(par[1], par[3]), stage_wpack(par[6], par[8])) if use_x3(H) else (None, None)
         # node_state = ones (digae_layer.py:260): the first half round sees identical rows, one kernel row per
         # (degree, feature class) pair does for all nodes of the pair
+        # quotient stages: while the rows of a half round are few distinct ones, it runs on one representative row per colour
+        quot = plan.quotient(xcls, 2 * rounds) if (QUOTIENT and FIRST_STAGE_TABLE and rounds > 0 and N > 0 and Whh_f.is_cuda) else []
+        if quot:
+            return StructEncoderFn._forward_quotient(ctx, plan, xcls, rounds, par, lw, lb, packs, quot)
         first = plan.first_stage_classes(xcls) if (FIRST_STAGE_TABLE and rounds > 0 and N > 0) else None
         h = None if first is not None else torch.ones(N, H, dtype=F32, device=dev)
         # table mode for the half round after the table one: bf16x3 H = 64 kernels, node ids and table rows fit a tagged 32-bit entry
@@ -241,12 +265,84 @@ class StructEncoderFn(torch.autograd.Function):
                     h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)], heavy=plan.heavy(rev))
         ctx.plan, ctx.xcls, ctx.rounds, ctx.packs, ctx.first = plan, xcls, rounds, packs, first
         ctx.par, ctx.lw, ctx.lb, ctx.states = par, lw, lb, states
+        ctx.quot = None
         return h
+
+    @staticmethod
+    def _forward_quotient(ctx, plan, xcls, rounds, par, lw, lb, packs, quot):
+        """Half rounds 1..len(quot) on one row per colour (inputs: the previous stage's table, stacked behind the representatives'
+        own rows), the table of the last one expanded to N rows, the remaining half rounds as usual."""
+        N, H, dev = plan.N, par[3].shape[1], par[3].device
+        states = []
+        table = torch.ones(1, H, dtype=F32, device=dev)
+        h = None
+        for k in range(2 * rounds):
+            rev = k % 2 == 1
+            w = par[5:] if rev else par[:5]
+            if k < len(quot):
+                st = quot[k]
+                h_cat = torch.cat([table.index_select(0, st['own']), table])
+                states.append(h_cat)
+                table = struct_stage_fwd(h_cat, st['ptr'], st['idx'], st['xcls'], w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)],
+                                         heavy=st['heavy'], n_rows=st['C'])
+                if k + 1 == len(quot) or k + 1 == 2 * rounds:
+                    h = torch.empty(N, H, dtype=F32, device=dev)
+                    _hip.call('mgv_class_expand', H, N, ptr(table), ptr(st['cid']), ptr(h))
+            else:
+                p, i = plan.csr(rev)
+                states.append(h)
+                h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)], heavy=plan.heavy(rev))
+        ctx.plan, ctx.xcls, ctx.rounds, ctx.packs, ctx.first = plan, xcls, rounds, packs, None
+        ctx.par, ctx.lw, ctx.lb, ctx.states = par, lw, lb, states
+        ctx.quot = quot
+        return h
+
+    @staticmethod
+    def _backward_quotient(ctx, gy):
+        plan, xcls, par, lw, lb, quot = ctx.plan, ctx.xcls, ctx.par, ctx.lw, ctx.lb, ctx.quot
+        H, dev = gy.shape[1], gy.device
+        acc = {}
+        for tag, w in (('f', par[:5]), ('r', par[5:])):
+            acc[tag] = {'dxtab': torch.zeros_like(w[0]), 'dWc': torch.zeros_like(w[1]), 'dbc': torch.zeros_like(w[2]),
+                        'dWhh': torch.zeros_like(w[3]), 'dbhh': torch.zeros_like(w[4])}
+        dlw = torch.zeros_like(lw) if lw is not None else None
+        dlb = torch.zeros_like(lb) if lb is not None else None
+        g_direct, g_agg = gy, None
+        gsum = None                                  # per-colour gradient sums entering the quotient stage below
+        for k in range(2 * ctx.rounds - 1, -1, -1):
+            rev = k % 2 == 1
+            w = par[5:] if rev else par[:5]
+            g = dict(acc['r' if rev else 'f'])
+            g['dln_w'], g['dln_b'] = dlw, dlb
+            if k >= len(quot):
+                p, i = plan.csr(rev)
+                g_direct, g_agg = struct_stage_bwd(ctx.states[k], p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, g_direct, g_agg, g,
+                                                   need_input_grad=(k > 0), wpack=ctx.packs[int(rev)], heavy=plan.heavy(rev))
+                continue
+            st = quot[k]
+            if gsum is None:
+                # the last quotient stage: per-colour sums of the per-node gradient (g_direct + the pull of g_agg over this stage's
+                # lists), colour runs cut into segments, partial rows summed level by level (mgv_seg_sum: list order, no atomics)
+                p, i = plan.csr(rev)
+                order, levels = st['sum_levels']
+                gsum = _seg_sums(H, levels, order, g_direct, g_agg, p, i)
+            gd_c, ga_c = struct_stage_bwd(ctx.states[k], st['ptr'], st['idx'], st['xcls'], w[0], w[1], w[2], w[3], w[4], lw, lb, gsum, None, g,
+                                          need_input_grad=(k > 0), wpack=ctx.packs[int(rev)], heavy=st['heavy'], n_rows=st['C'])
+            if k > 0:
+                # colour sums for stage k-1: a colour there collects the own-row gradients of the representatives that own it and the
+                # aggregate gradients of those that list it (deterministic gathers over the colour-level lists)
+                gsum = _seg_sums(H, st['own_levels'], st['own_rows'], gd_c) + _seg_sums(H, st['ent_levels'], st['ent_rows'], ga_c)
+        ctx.states = None
+        f, r = acc['f'], acc['r']
+        return (None, None, None, f['dxtab'], f['dWc'], f['dbc'], f['dWhh'], f['dbhh'],
+                r['dxtab'], r['dWc'], r['dbc'], r['dWhh'], r['dbhh'], dlw, dlb)
 
     @staticmethod
     def backward(ctx, gy):
         plan, xcls, par, lw, lb = ctx.plan, ctx.xcls, ctx.par, ctx.lw, ctx.lb
         gy = gy.contiguous()
+        if ctx.quot:
+            return StructEncoderFn._backward_quotient(ctx, gy)
         acc = {}
         for tag, w in (('f', par[:5]), ('r', par[5:])):
             acc[tag] = {'dxtab': torch.zeros_like(w[0]), 'dWc': torch.zeros_like(w[1]), 'dbc': torch.zeros_like(w[2]),

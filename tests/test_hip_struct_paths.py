@@ -95,3 +95,50 @@ def test_struct_paths_agree_on_a_hub_graph():
     # the (degree, class)-table first half round is the same arithmetic as the per-node launch
     for precision, tol in (('f32', 2e-4), ('x3', 2e-3)):
         assert worst(runs[precision, 'table'], runs[precision, 'full'])[0] <= tol, (precision, worst(runs[precision, 'table'], runs[precision, 'full']))
+
+
+@pytest.mark.parametrize('ctype,H', [('aig', 64), ('xmg', 64), ('mig', 32), ('aig', 16)])
+def test_quotient_stages_equal_the_per_node_stages(ctype, H):
+    """Early half rounds run on one row per colour (GraphPlan.quotient: rows that are identical by construction).  Same encoder,
+    same batch, with and without: embeddings to rounding (a colour's row is computed from the same inputs in another tile), every
+    parameter gradient to the rounding of its sums (per-colour sums first, instead of per-tile sums)."""
+    dev = _dev()
+    import deepgate
+    from deepgate import ops, synthetic as syn
+    from deepgate.graph_plan import GraphPlan
+    arrays = syn.collate([syn.make_graph(ctype, 512 + 120 * 60, 60, 900 + i, n_inputs=512) for i in range(3)])
+    n = arrays['num_nodes']
+    ei = torch.from_numpy(arrays['edge_index']).to(dev)
+    x = torch.from_numpy(arrays['x']).to(dev)
+    plan = GraphPlan(ei, n)
+    xcls = x[:, 1].to(torch.uint8).contiguous()
+    quot = plan.quotient(xcls, 4)
+    assert len(quot) >= 2 and quot[0]['C'] <= 8, [s['C'] for s in quot]
+    res = {}
+    for flag in (True, False):
+        old = ops.QUOTIENT
+        ops.QUOTIENT = flag
+        try:
+            torch.manual_seed(11)
+            enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=H, s_rounds=2, t_rounds=2, layernorm=True).to(dev)
+            s, t = enc(x, x, ei)
+            gs = torch.randn(n, H, device=dev, generator=torch.Generator(dev).manual_seed(5))
+            gt = torch.randn(n, H, device=dev, generator=torch.Generator(dev).manual_seed(6))
+            ((s * gs).sum() + (t * gt).sum()).backward()
+            res[flag] = [s.detach(), t.detach()] + [p.grad.detach().clone() for p in enc.parameters()]
+            names = ['s', 't'] + [k for k, _ in enc.named_parameters()]
+        finally:
+            ops.QUOTIENT = old
+    for nm, a, b in zip(names, res[True], res[False]):
+        scale = float(b.abs().max())
+        if scale > 1e-6:
+            tol = 2e-5 if nm in ('s', 't') else 1e-4      # (a member's neighbours may come in another order than its representative's)
+            assert float((a - b).abs().max()) <= tol * scale, (nm, float((a - b).abs().max()) / scale)
+    # and twice the same: bit-identical (segment sums in list order, gathers over the colour lists: no atomics)
+    torch.manual_seed(11)
+    enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=H, s_rounds=2, t_rounds=2, layernorm=True).to(dev)
+    s, t = enc(x, x, ei)
+    ((s * gs).sum() + (t * gt).sum()).backward()
+    again = [s.detach(), t.detach()] + [p.grad.detach().clone() for p in enc.parameters()]
+    if H == 64:          # (the H = 32 / 16 backward kernels add their weight gradients with float atomics)
+        assert all(torch.equal(a, b) for a, b in zip(again, res[True]))
