@@ -142,8 +142,8 @@ class GraphPlan:
         if self.has_levels:
             self.heavy_segments(True, inactive_only=True)
             self.heavy_segments(True, active_by_level=True)
-        if xcls is not None and self.N > 0 and quotient_stages:
-            self.quotient(xcls, quotient_stages)
+        if xcls is not None and self.N > 0 and quotient_stages and self.quotient(xcls, quotient_stages):
+            return self                      # the quotient stages replace the first-stage table and its tagged lists
         if xcls is not None and self.N > 0:
             first = self.first_stage_classes(xcls)
             if first is not None and first[1] <= 256 and self.N < (1 << 24):
@@ -238,7 +238,7 @@ class GraphPlan:
         self._stage1 = (key, out)
         return out
 
-    QUOTIENT_FRACTION = 4      # a half round runs on distinct rows only while they are at most N / 4
+    QUOTIENT_FRACTION = float(os.environ.get('MGV_QUOTIENT_FRACTION', '4'))      # a half round runs on distinct rows only while they are at most N / 4
 
     def quotient(self, xcls, max_stages):
         """Quotient stages of the structural encoder.  Every node starts from the same state (ones, digae_layer.py:260), so after
@@ -284,7 +284,10 @@ class GraphPlan:
                 C = int(uniq.numel())
                 if C * self.QUOTIENT_FRACTION > N:
                     break
-                rep = torch.full((C,), N, **i64).scatter_reduce_(0, inv, node, 'amin')
+                # representative = first member (stable sort by colour; a scatter-min onto a handful of addresses costs 27 ms)
+                by_colour = torch.sort(inv, stable=True).indices
+                members = torch.bincount(inv, minlength=C)
+                rep = by_colour[torch.cumsum(members, 0) - members]
                 ri = rep[inv]
                 same = (xc == xc[ri]) & (prev == prev[ri]) & (h1 == h1[ri]) & (h2 == h2[ri]) & (deg == deg[ri])
                 if not bool(same.all()):
@@ -310,6 +313,8 @@ class GraphPlan:
                                    ent_rows=row[ent_o.long()].to(torch.int32).contiguous() if n_ent else torch.zeros(1, dtype=torch.int32, device=dev),
                                    ent_levels=ent_levels))
                 prev, Cp = inv, C
+                if C * 32 * self.QUOTIENT_FRACTION > N:
+                    break                    # colours multiply by the fan-in / fan-out per half round: the next one would not qualify
             if stages:
                 stages[-1]['sum_levels'] = self.class_sum_levels(stages[-1]['cid'], stages[-1]['C'])
         self._quotient = (key, stages)

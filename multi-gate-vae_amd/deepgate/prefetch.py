@@ -97,9 +97,10 @@ class BatchPrefetcher:
     workers  : host threads that collate / copy / plan (numpy releases the GIL in the large copies)
     depth    : batches in flight (>= workers)
     skip     : fields left out (e.g. 'neg_edge_index' when negatives are drawn on the device)
+    quotient_stages : half rounds of the structural encoder (2 x rounds) whose colour classes are prepared with the plan (GraphPlan.quotient)
     """
 
-    def __init__(self, chunks, device, gate_ids=None, workers=2, depth=None, skip=()):
+    def __init__(self, chunks, device, gate_ids=None, workers=2, depth=None, skip=(), quotient_stages=8):
         self.chunks = iter(chunks)
         self.device = torch.device(device)
         self.cuda = self.device.type == 'cuda'
@@ -107,6 +108,7 @@ class BatchPrefetcher:
         self.workers = max(int(workers), 1)
         self.depth = max(int(depth) if depth is not None else self.workers + 1, self.workers)
         self.keys = [k for k in _KEYS if k not in skip]
+        self.quotient_stages = int(quotient_stages)
         self._free = queue.Queue()
         for _ in range(self.depth + 1):
             self._free.put(_Staging(self.cuda))
@@ -151,7 +153,7 @@ class BatchPrefetcher:
             self._free.put(st)
             if self.gate_ids is not None:
                 plan = plan_of(b, self.gate_ids)        # its few host read-backs wait on THIS stream only
-                plan.warm(plan.xcls)                    # ... and those of the caches the step would build lazily
+                plan.warm(plan.xcls, self.quotient_stages)     # ... and those of the caches the step would build lazily
                 if getattr(b, 'tt_pair_index', None) is not None and b.tt_pair_index.shape[1] >= 2:
                     from . import ops
                     b._mgv_pair_lists = ops.pair_lists(b.tt_pair_index, b.x.shape[0])

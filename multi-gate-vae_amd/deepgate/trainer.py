@@ -210,6 +210,12 @@ class Trainer():
         loss_status['confusion'] = self.model.last_confusion
         return loss_status
 
+    def _encoder_half_rounds(self):
+        """2 x rounds of the model's structural encoder (what GraphPlan.quotient is asked for), 8 when it cannot be told."""
+        enc = getattr(self.model, getattr(self.model, 'ENCODER_ATTR', 'struct_encoder'), None)
+        conv = getattr(enc, 'source_conv', None)
+        return 2 * int(getattr(conv, 'num_rounds', 4))
+
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream()
@@ -294,7 +300,7 @@ class Trainer():
                 # collate, host-to-device copy and plan build of the next batches run on worker threads / their own HIP streams
                 # beside the current step (deepgate/prefetch.py); the reference does `batch.to(device)` inside the loop (trainer.py:223)
                 batches = BatchPrefetcher(loader.chunks(), self.device, gate_ids=[g for _, g in getattr(self.model, 'GATES', [])] or None,
-                                          workers=max(self.num_workers, 2))
+                                          workers=max(self.num_workers, 2), quotient_stages=self._encoder_half_rounds())
                 for iter_id, batch in enumerate(batches):
                     time_stamp = time.time()
                     if phase == 'train':
