@@ -253,9 +253,10 @@ class GraphPlan:
             own_rows/own_levels, ent_rows/ent_levels: per colour of stage t-1 the representatives that own it / whose lists name it,
                      as segment tables of mgv_seg_sum (backward)
         and the last stage also `sum_levels` (class_sum_levels) for the per-colour sums of the per-node gradient.
-        Neighbour multisets are compared through two independent 64-bit sums of random per-colour values (a colour pair
-        collides with probability 2^-128); the 64-bit key they are folded into is checked member by member against each
-        colour's representative, refinement stops at the first disagreement.  Cached per xcls tensor."""
+        Grouping is proposed by a 64-bit key (two sums of random per-colour values over the neighbour list, folded with the own
+        colour, class and degree) and then CHECKED exactly: every member against its colour's representative, list entry by list
+        entry (lists sorted by colour); refinement stops at the first disagreement, so a key collision costs speed, never
+        correctness.  Cached per xcls tensor."""
         key = (xcls.data_ptr(), int(xcls.numel()), int(max_stages))
         hit = getattr(self, '_quotient', None)
         if hit is not None and hit[0] == key:
@@ -288,9 +289,14 @@ class GraphPlan:
                 by_colour = torch.sort(inv, stable=True).indices
                 members = torch.bincount(inv, minlength=C)
                 rep = by_colour[torch.cumsum(members, 0) - members]
+                # exact check of the grouping (the sums above only PROPOSE it): every member has its representative's feature class,
+                # previous colour, degree and — list entry by list entry, both lists sorted by colour — neighbour colours
                 ri = rep[inv]
-                same = (xc == xc[ri]) & (prev == prev[ri]) & (h1 == h1[ri]) & (h2 == h2[ri]) & (deg == deg[ri])
-                if not bool(same.all()):
+                same = (xc == xc[ri]) & (prev == prev[ri]) & (deg == deg[ri])
+                sorted_col = torch.sort(owner * (Cp + 1) + pn).values - owner * (Cp + 1)      # each node's list, colours ascending
+                k_in_list = torch.arange(owner.numel(), **i64) - pl[:-1][owner]
+                lists_same = sorted_col == sorted_col[(pl[:-1][ri[owner]] + k_in_list).clamp_(max=max(owner.numel() - 1, 0))]
+                if not (bool(same.all()) and bool(lists_same.all())):
                     break
                 dr = deg[rep]
                 rptr = torch.zeros(C + 1, **i64)

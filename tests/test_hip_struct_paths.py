@@ -142,3 +142,32 @@ def test_quotient_stages_equal_the_per_node_stages(ctype, H):
     again = [s.detach(), t.detach()] + [p.grad.detach().clone() for p in enc.parameters()]
     if H == 64:          # (the H = 32 / 16 backward kernels add their weight gradients with float atomics)
         assert all(torch.equal(a, b) for a, b in zip(again, res[True]))
+
+
+def test_segment_sums_against_float64():
+    """mgv_seg_sum through GraphPlan.class_sum_levels: per-colour sums of (direct[i] + sum of agg over i's list) with one colour that
+    holds half the nodes, singletons and an empty colour, against a float64 index_add; and bit-identical twice."""
+    dev = _dev()
+    from deepgate import ops
+    from deepgate.graph_plan import GraphPlan
+    g = torch.Generator().manual_seed(3)
+    N, E, H, C = 50000, 120000, 64, 700
+    ei = torch.stack([torch.randint(0, N, (E,), generator=g), torch.randint(0, N, (E,), generator=g)]).to(dev)
+    plan = GraphPlan(ei, N)
+    cid = torch.randint(1, C - 1, (N,), generator=g)
+    cid[torch.rand(N, generator=g) < 0.5] = 0                       # a colour with half the nodes; colour C-1 stays empty
+    cid = cid.to(dev)
+    direct = torch.randn(N, H, generator=g).to(dev)
+    agg = torch.randn(N, H, generator=g).to(dev)
+    order, levels = plan.class_sum_levels(cid, C)
+    p, i = plan.csr(False)
+    got = ops._seg_sums(H, levels, order, direct, agg, p, i)
+    dy = direct.double().clone()
+    dy.index_add_(0, plan.in_dst.long(), agg.double()[plan.in_src.long()])
+    ref = torch.zeros(C, H, dtype=torch.float64, device=dev).index_add_(0, cid.long(), dy)
+    assert got.shape == (C, H) and float(got[C - 1].abs().max()) == 0.0
+    assert float((got.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert torch.equal(got, ops._seg_sums(H, levels, order, direct, agg, p, i))
+    plain = ops._seg_sums(H, levels, order, direct)
+    ref2 = torch.zeros(C, H, dtype=torch.float64, device=dev).index_add_(0, cid.long(), direct.double())
+    assert float((plain.double() - ref2).abs().max()) <= 2e-5 * float(ref2.abs().max())

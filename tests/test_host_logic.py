@@ -267,3 +267,57 @@ def test_prefetcher_collates_like_collate_and_keeps_order():
         assert b._mgv_plan.has_levels and b._mgv_plan.N == ref['num_nodes']
     skipped = next(iter(BatchPrefetcher(iter(chunks[:1]), 'cpu', skip=('neg_edge_index',))))
     assert not hasattr(skipped, 'neg_edge_index') and not hasattr(skipped, '_mgv_plan')
+
+
+@pytest.mark.parametrize('ctype', ['aig', 'xmg'])
+def test_quotient_colours_equal_brute_force_refinement(ctype):
+    """GraphPlan.quotient (host logic of the structural encoder's quotient stages): the colours of half round t equal colour
+    refinement done literally — (feature class, previous colour, sorted tuple of the neighbours' previous colours) over the in-CSR for odd t,
+    the out-CSR for even t — and a representative's list names its neighbours' previous colours."""
+    from deepgate import synthetic as syn
+    from deepgate.graph_plan import GraphPlan
+    a = syn.collate([syn.make_graph(ctype, 200 + 30 * 40, 40, 5 + i, n_inputs=200) for i in range(2)])
+    N, ei = a['num_nodes'], a['edge_index']
+    plan = GraphPlan(torch.from_numpy(ei), N)
+    xcls = torch.from_numpy(a['x'][:, 1].astype('uint8'))
+    old = GraphPlan.QUOTIENT_FRACTION
+    GraphPlan.QUOTIENT_FRACTION = 1.5                      # small graphs: let three half rounds qualify
+    try:
+        q = plan.quotient(xcls, 3)
+    finally:
+        GraphPlan.QUOTIENT_FRACTION = old
+    assert len(q) >= 2
+    col = [0] * N
+    for t, s in enumerate(q, start=1):
+        src, dst = (ei[1], ei[0]) if t % 2 == 0 else (ei[0], ei[1])
+        nb = [[] for _ in range(N)]
+        for u, v in zip(src.tolist(), dst.tolist()):
+            nb[v].append(col[u])
+        keys = [(int(xcls[i]), col[i], tuple(sorted(nb[i]))) for i in range(N)]
+        ids = {}
+        for kk in keys:
+            ids.setdefault(kk, len(ids))
+        cid = s['cid'].tolist()
+        assert len(set(zip((ids[kk] for kk in keys), cid))) == len(ids) == s['C'], t          # the same partition
+        # representatives' lists: entries = C + previous colour (in the numbering of stage t-1: q[t-2]['cid'], or 0)
+        prev_cid = q[t - 2]['cid'].tolist() if t > 1 else [0] * N
+        first = {}
+        for i, c in enumerate(cid):
+            first.setdefault(c, i)
+        ptr, idx, own = s['ptr'].tolist(), s['idx'].tolist(), s['own'].tolist()
+        for c in range(s['C']):
+            r = first[c]
+            assert own[c] == prev_cid[r]
+            src_nodes = [u for u, v in zip(src.tolist(), dst.tolist()) if v == r]
+            assert sorted(idx[ptr[c]:ptr[c + 1]]) == sorted(s['C'] + prev_cid[u] for u in src_nodes), (t, c)
+        col = [ids[kk] for kk in keys]
+    # segment tables of the per-colour sums: runs of <= 64 members of one colour, in colour order, down to one row per colour
+    order, levels = q[-1]['sum_levels']
+    cid = q[-1]['cid']
+    assert sorted(order.tolist()) == list(range(N)) and bool((cid[order.long()][1:] >= cid[order.long()][:-1]).all())
+    n_items = N
+    for n_seg, sp in levels:
+        sp = sp.tolist()
+        assert len(sp) == n_seg + 1 and sp[0] == 0 and sp[-1] == n_items and all(0 <= b - a_ <= 64 for a_, b in zip(sp[:-1], sp[1:]))
+        n_items = n_seg
+    assert n_items == q[-1]['C']
