@@ -263,6 +263,7 @@ class GraphPlan:
             return hit[1]
         N, dev = self.N, self.device
         stages = []
+        self._check_status()                 # (edge ids outside [0, N) raise here, before the lists are read)
         if N > 0 and self.E > 0:
             i64 = dict(dtype=torch.int64, device=dev)
             gen = torch.Generator(device=dev)
@@ -270,24 +271,26 @@ class GraphPlan:
             xc = xcls.long()
             prev, Cp = torch.zeros(N, **i64), 1
             node = torch.arange(N, **i64)
+            owners = {}                      # the row of every CSR slot, per direction
             for t_ in range(1, max_stages + 1):
                 rev = t_ % 2 == 0
                 p, idx = self.csr(rev)
                 pl, il = p.long(), idx.long()
                 deg = pl[1:] - pl[:-1]
-                owner = torch.repeat_interleave(node, deg)
+                owner = owners.get(rev)
+                if owner is None:
+                    owner = owners[rev] = torch.repeat_interleave(node, deg) if rev else self.in_dst.long()
                 f = torch.randint(1, 1 << 62, (3, Cp + 1), generator=gen, **i64)
                 pn = prev[il]
                 h1 = torch.zeros(N, **i64).index_add_(0, owner, f[0][pn])
                 h2 = torch.zeros(N, **i64).index_add_(0, owner, f[1][pn])
                 mix = h1 * 0x1E3779B97F4A7C15 + h2 + f[2][prev] + xc * 0x632BE59BD9B4E019 + deg * 0x2545F4914F6CDD1D
-                uniq, inv = torch.unique(mix, return_inverse=True)
+                uniq, inv, members = torch.unique(mix, return_inverse=True, return_counts=True)
                 C = int(uniq.numel())
                 if C * self.QUOTIENT_FRACTION > N:
                     break
                 # representative = first member (stable sort by colour; a scatter-min onto a handful of addresses costs 27 ms)
                 by_colour = torch.sort(inv, stable=True).indices
-                members = torch.bincount(inv, minlength=C)
                 rep = by_colour[torch.cumsum(members, 0) - members]
                 # exact check of the grouping (the sums above only PROPOSE it): every member has its representative's feature class,
                 # previous colour, degree and — list entry by list entry, both lists sorted by colour — neighbour colours
@@ -319,21 +322,25 @@ class GraphPlan:
                                    ent_rows=row[ent_o.long()].to(torch.int32).contiguous() if n_ent else torch.zeros(1, dtype=torch.int32, device=dev),
                                    ent_levels=ent_levels))
                 prev, Cp = inv, C
+                last_sorted = (by_colour, members)
                 if C * 32 * self.QUOTIENT_FRACTION > N:
                     break                    # colours multiply by the fan-in / fan-out per half round: the next one would not qualify
             if stages:
-                stages[-1]['sum_levels'] = self.class_sum_levels(stages[-1]['cid'], stages[-1]['C'])
+                stages[-1]['sum_levels'] = self.class_sum_levels(stages[-1]['cid'], stages[-1]['C'], presorted=last_sorted)
         self._quotient = (key, stages)
         return stages
 
-    def class_sum_levels(self, cid, C, seg=64):
+    def class_sum_levels(self, cid, C, seg=64, presorted=None):
         """Segment tables of mgv_seg_sum for per-colour row sums: (order [N] int32 = nodes sorted by colour, [(n_seg, seg_ptr)] per
         level).  Level 1 cuts every colour's run of members into segments of <= seg, level l+1 does the same with level l's
         partial rows, until every colour is one segment; the last level's rows are the colours in order."""
         dev = self.device
         i64 = dict(dtype=torch.int64, device=dev)
-        order = torch.sort(cid.long(), stable=True).indices.to(torch.int32).contiguous()
-        counts = torch.bincount(cid.long(), minlength=C)
+        if presorted is not None:            # (items already sorted by colour, members per colour)
+            order, counts = presorted[0].to(torch.int32).contiguous(), presorted[1]
+        else:
+            order = torch.sort(cid.long(), stable=True).indices.to(torch.int32).contiguous()
+            counts = torch.bincount(cid.long(), minlength=C)
         levels = []
         while True:
             nseg = torch.clamp((counts + seg - 1) // seg, min=1)         # (a colour nobody carries still gets its zero row)
