@@ -238,7 +238,7 @@ class GraphPlan:
         self._stage1 = (key, out)
         return out
 
-    QUOTIENT_FRACTION = float(os.environ.get('MGV_QUOTIENT_FRACTION', '4'))      # a half round runs on distinct rows only while they are at most N / 4
+    QUOTIENT_FRACTION = float(os.environ.get('MGV_QUOTIENT_FRACTION', '3'))      # a half round runs on distinct rows only while they are at most N / 3
 
     def quotient(self, xcls, max_stages):
         """Quotient stages of the structural encoder.  Every node starts from the same state (ones, digae_layer.py:260), so after
