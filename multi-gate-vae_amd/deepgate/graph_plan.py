@@ -323,7 +323,7 @@ class GraphPlan:
                                    ent_levels=ent_levels))
                 prev, Cp = inv, C
                 last_sorted = (by_colour, members)
-                if C * 32 * self.QUOTIENT_FRACTION > N:
+                if C * 64 * self.QUOTIENT_FRACTION > N:
                     break                    # colours multiply by the fan-in / fan-out per half round: the next one would not qualify
             if stages:
                 stages[-1]['sum_levels'] = self.class_sum_levels(stages[-1]['cid'], stages[-1]['C'], presorted=last_sorted)
