@@ -371,6 +371,10 @@ def main():
             'value_with_plan_build': world * B / (elapsed / a.steps + plan_ms_steady * 1e-3),
             'losses': losses, 'roofline': roof,
         }
+        quot = batch._mgv_plan.quotient(batch._mgv_plan.xcls, 2 * rounds) if ops.QUOTIENT else []
+        out['struct_encoder'] = {'half_rounds': 2 * rounds, 'rows_per_half_round': [s['C'] for s in quot] + [N] * (2 * rounds - len(quot)),
+                                 'note': 'every node starts from ones (digae_layer.py:260): the first half rounds have few distinct rows (colour '
+                                         'refinement) and are computed on one row per colour, exactly (DESIGN.md 4.3; MGV_QUOTIENT=0 turns it off)'}
         if fresh is not None:
             out['value_fresh_batches'] = fresh['value']
             out['fresh_batches'] = fresh
