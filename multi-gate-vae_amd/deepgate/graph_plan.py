@@ -257,10 +257,9 @@ class GraphPlan:
         colour, class and degree) and then CHECKED exactly: every member against its colour's representative, list entry by list
         entry (lists sorted by colour); refinement stops at the first disagreement, so a key collision costs speed, never
         correctness.  Cached per xcls tensor."""
-        key = (xcls.data_ptr(), int(xcls.numel()), int(max_stages))
         hit = getattr(self, '_quotient', None)
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        if hit is not None and hit[0] is xcls and hit[1] == int(max_stages):      # (the tensor itself: an address can be reused)
+            return hit[2]
         N, dev = self.N, self.device
         stages = []
         self._check_status()                 # (edge ids outside [0, N) raise here, before the lists are read)
@@ -327,7 +326,7 @@ class GraphPlan:
                     break                    # colours multiply by the fan-in / fan-out per half round: the next one would not qualify
             if stages:
                 stages[-1]['sum_levels'] = self.class_sum_levels(stages[-1]['cid'], stages[-1]['C'], presorted=last_sorted)
-        self._quotient = (key, stages)
+        self._quotient = (xcls, int(max_stages), stages)
         return stages
 
     def class_sum_levels(self, cid, C, seg=64, presorted=None):
