@@ -415,6 +415,16 @@ int mgv_plan_tiles(int K, int T, int L, int64_t n_active, const int32_t* key_sta
 int mgv_plan_pairs(int64_t N, const int32_t* in_ptr, const uint8_t* xcls, int32_t* present, int32_t* rank, int32_t* scan_scratch, int32_t* cid,
                    int32_t* cls_deg, uint8_t* cls_x, int32_t* status, void* stream);
 
+/* ---- colour refinement for the quotient stages of the structural encoder (GraphPlan.quotient; digae_layer.py:260: every node starts
+ * from ones, so after a half round a node's row depends on (feature class, previous colour, multiset of neighbour colours) only).
+ * keys: a 63-bit grouping key per node (f = int64 [3][fstride] random values per previous colour; sums over the list: order
+ * independent).  check: exact comparison of every node with its group's representative rep[cid[i]] — class, previous colour, degree,
+ * neighbour-colour multiset; flags[0] = 1 on any difference, flags[1] = nodes with lists beyond 48 entries, left to the caller. */
+int mgv_colour_keys(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const int64_t* f, int64_t fstride,
+                    const uint8_t* xcls, int64_t* key, void* stream);
+int mgv_colour_check(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const uint8_t* xcls, const int64_t* cid,
+                     const int64_t* rep, int32_t* flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -343,6 +343,47 @@ __global__ __launch_bounds__(256) void k_pair_table(const int32_t* present, cons
 
 static inline int blocks_for(int64_t n, int per = 256, int cap = 256 * 64) { const int64_t b = (n + per - 1) / per; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
 
+// ---- colour refinement (GraphPlan.quotient): a node's colour after a half round is (feature class, previous colour, multiset of its
+// neighbours' previous colours).  k_colour_keys folds that into a 64-bit grouping key (two sums of random per-colour values: order
+// independent); k_colour_check then compares every node with its group's representative EXACTLY — class, previous colour, degree and
+// the two neighbour-colour multisets (every colour of the node's list must occur equally often in both lists) — so a key collision is
+// found, never believed.  Lists beyond kColourCheckMax entries are left to the caller's sort-based check (n_long counts them).
+constexpr int kColourCheckMax = 48;
+
+__global__ __launch_bounds__(256) void k_colour_keys(int64_t N, const int32_t* ptr, const int32_t* idx, const int32_t* prev, const int64_t* f, int64_t fstride,
+                                                     const uint8_t* xcls, int64_t* key) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int e0 = ptr[i], e1 = ptr[i + 1];
+    unsigned long long h1 = 0, h2 = 0;
+    for (int e = e0; e < e1; ++e) {
+        const int c = prev[idx[e]];
+        h1 += (unsigned long long)f[c];
+        h2 += (unsigned long long)f[fstride + c];
+    }
+    const unsigned long long k = h1 * 0x1E3779B97F4A7C15ull + h2 + (unsigned long long)f[2 * fstride + prev[i]] + (unsigned long long)xcls[i] * 0x632BE59BD9B4E019ull +
+                                 (unsigned long long)(e1 - e0) * 0x2545F4914F6CDD1Dull;
+    key[i] = (int64_t)(k >> 1);          // non-negative: torch.unique sorts signed values
+}
+
+__global__ __launch_bounds__(256) void k_colour_check(int64_t N, const int32_t* ptr, const int32_t* idx, const int32_t* prev, const uint8_t* xcls,
+                                                      const int64_t* cid, const int64_t* rep, int32_t* flags) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int64_t r = rep[cid[i]];
+    if (r == i) return;
+    const int a0 = ptr[i], a1 = ptr[i + 1], b0 = ptr[r], b1 = ptr[r + 1];
+    if (xcls[i] != xcls[r] || prev[i] != prev[r] || a1 - a0 != b1 - b0) { flags[0] = 1; return; }
+    const int d = a1 - a0;
+    if (d > kColourCheckMax) { atomicAdd(flags + 1, 1); return; }
+    for (int k = 0; k < d; ++k) {
+        const int c = prev[idx[a0 + k]];
+        int na = 0, nb = 0;
+        for (int m = 0; m < d; ++m) { na += prev[idx[a0 + m]] == c; nb += prev[idx[b0 + m]] == c; }
+        if (na != nb) { flags[0] = 1; return; }
+    }
+}
+
 }  // namespace mgv
 
 using namespace mgv;
@@ -517,5 +558,25 @@ extern "C" int mgv_plan_pairs(int64_t N, const int32_t* in_ptr, const uint8_t* x
     if (rc != MGV_OK) return rc;
     hipLaunchKernelGGL(k_pair_ids, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, in_ptr, xcls, rank, cid);
     hipLaunchKernelGGL(k_pair_table, dim3(256), dim3(256), 0, st, present, rank, cls_deg, cls_x);
+    MGV_LAUNCH_RET();
+}
+
+/* Colour refinement of GraphPlan.quotient (ops.StructEncoderFn's quotient stages).  keys: key[i] = 63-bit grouping key of node i from
+ * its feature class, previous colour prev[i], degree and the multiset of its neighbours' previous colours (f = int64 [3][fstride]
+ * random values per previous colour).  check: flags[0] = 1 if some node differs from its group's representative rep[cid[i]] in class,
+ * previous colour, degree or neighbour-colour multiset (exact comparison); flags[1] = number of nodes whose lists are longer than 48
+ * entries and were NOT compared (the caller checks those by sorting).  flags must be zeroed by the caller. */
+extern "C" int mgv_colour_keys(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const int64_t* f, int64_t fstride,
+                               const uint8_t* xcls, int64_t* key, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && nbr_ptr && prev && f && xcls && key);
+    if (N == 0) return MGV_OK;
+    hipLaunchKernelGGL(k_colour_keys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), N, nbr_ptr, nbr_idx, prev, f, fstride, xcls, key);
+    MGV_LAUNCH_RET();
+}
+extern "C" int mgv_colour_check(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const uint8_t* xcls, const int64_t* cid,
+                                const int64_t* rep, int32_t* flags, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && nbr_ptr && prev && xcls && cid && rep && flags);
+    if (N == 0) return MGV_OK;
+    hipLaunchKernelGGL(k_colour_check, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), N, nbr_ptr, nbr_idx, prev, xcls, cid, rep, flags);
     MGV_LAUNCH_RET();
 }

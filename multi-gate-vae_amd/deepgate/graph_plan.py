@@ -276,14 +276,22 @@ class GraphPlan:
                 p, idx = self.csr(rev)
                 pl, il = p.long(), idx.long()
                 deg = pl[1:] - pl[:-1]
-                owner = owners.get(rev)
-                if owner is None:
-                    owner = owners[rev] = torch.repeat_interleave(node, deg) if rev else self.in_dst.long()
                 f = torch.randint(1, 1 << 62, (3, Cp + 1), generator=gen, **i64)
-                pn = prev[il]
-                h1 = torch.zeros(N, **i64).index_add_(0, owner, f[0][pn])
-                h2 = torch.zeros(N, **i64).index_add_(0, owner, f[1][pn])
-                mix = h1 * 0x1E3779B97F4A7C15 + h2 + f[2][prev] + xc * 0x632BE59BD9B4E019 + deg * 0x2545F4914F6CDD1D
+                if self.hip:
+                    # grouping key and exact check by the plan builder's kernels (csrc/plan_build.hip: mgv_colour_keys / _check)
+                    from . import _hip
+                    from ._hip import ptr
+                    prev32 = prev.to(torch.int32)
+                    mix = torch.empty(N, **i64)
+                    _hip.call('mgv_colour_keys', N, ptr(p), ptr(idx), ptr(prev32), ptr(f), Cp + 1, ptr(xcls), ptr(mix))
+                else:
+                    owner = owners.get(rev)
+                    if owner is None:
+                        owner = owners[rev] = torch.repeat_interleave(node, deg) if rev else self.in_dst.long()
+                    pn = prev[il]
+                    h1 = torch.zeros(N, **i64).index_add_(0, owner, f[0][pn])
+                    h2 = torch.zeros(N, **i64).index_add_(0, owner, f[1][pn])
+                    mix = h1 * 0x1E3779B97F4A7C15 + h2 + f[2][prev] + xc * 0x632BE59BD9B4E019 + deg * 0x2545F4914F6CDD1D
                 uniq, inv, members = torch.unique(mix, return_inverse=True, return_counts=True)
                 C = int(uniq.numel())
                 if C * self.QUOTIENT_FRACTION > N:
@@ -291,15 +299,27 @@ class GraphPlan:
                 # representative = first member (stable sort by colour; a scatter-min onto a handful of addresses costs 27 ms)
                 by_colour = torch.sort(inv, stable=True).indices
                 rep = by_colour[torch.cumsum(members, 0) - members]
-                # exact check of the grouping (the sums above only PROPOSE it): every member has its representative's feature class,
-                # previous colour, degree and — list entry by list entry, both lists sorted by colour — neighbour colours
-                ri = rep[inv]
-                same = (xc == xc[ri]) & (prev == prev[ri]) & (deg == deg[ri])
-                sorted_col = torch.sort(owner * (Cp + 1) + pn).values - owner * (Cp + 1)      # each node's list, colours ascending
-                k_in_list = torch.arange(owner.numel(), **i64) - pl[:-1][owner]
-                lists_same = sorted_col == sorted_col[(pl[:-1][ri[owner]] + k_in_list).clamp_(max=max(owner.numel() - 1, 0))]
-                if not (bool(same.all()) and bool(lists_same.all())):
-                    break
+                # exact check of the grouping (the key above only PROPOSES it): every member has its representative's feature class,
+                # previous colour, degree and neighbour-colour multiset
+                n_long = 1
+                if self.hip:
+                    flags = torch.zeros(2, dtype=torch.int32, device=dev)
+                    _hip.call('mgv_colour_check', N, ptr(p), ptr(idx), ptr(prev32), ptr(xcls), ptr(inv), ptr(rep), ptr(flags))
+                    bad, n_long = flags.tolist()
+                    if bad:
+                        break
+                if n_long:                   # (CPU plan, or lists too long for the kernel's pairwise comparison): both lists sorted by colour
+                    owner = owners.get(rev)
+                    if owner is None:
+                        owner = owners[rev] = torch.repeat_interleave(node, deg) if rev else self.in_dst.long()
+                    pn = prev[il]
+                    ri = rep[inv]
+                    same = (xc == xc[ri]) & (prev == prev[ri]) & (deg == deg[ri])
+                    sorted_col = torch.sort(owner * (Cp + 1) + pn).values - owner * (Cp + 1)      # each node's list, colours ascending
+                    k_in_list = torch.arange(owner.numel(), **i64) - pl[:-1][owner]
+                    lists_same = sorted_col == sorted_col[(pl[:-1][ri[owner]] + k_in_list).clamp_(max=max(owner.numel() - 1, 0))]
+                    if not (bool(same.all()) and bool(lists_same.all())):
+                        break
                 dr = deg[rep]
                 rptr = torch.zeros(C + 1, **i64)
                 rptr[1:] = torch.cumsum(dr, 0)

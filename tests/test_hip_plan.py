@@ -229,3 +229,36 @@ def test_plan_build_time_at_config_2():
         times.append((time.time() - t0) * 1e3)
     print('plan build, 16 x 65,536-node graphs: cold %.1f ms, warm %.2f ms' % (times[0], min(times[1:])))
     assert min(times[1:]) < 50.0
+
+
+@pytest.mark.gpu
+def test_device_colour_refinement_equals_the_host_one():
+    """GraphPlan.quotient on the device (mgv_colour_keys / mgv_colour_check + torch sorts) against the torch-only host path: the same
+    partition of the nodes per half round; twin hubs with 80 consumers each (lists beyond the kernel's pairwise check: the sort-based
+    check decides) land in one colour."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from deepgate import synthetic as syn
+    from deepgate.graph_plan import GraphPlan
+    a = syn.collate([syn.make_graph('aig', 256 + 64 * 40, 40, 21 + i, n_inputs=256) for i in range(3)])
+    ei, n = a['edge_index'], a['num_nodes']
+    lv = a['forward_level']
+    later = np.nonzero(lv >= 2)[0]
+    rng = np.random.Generator(np.random.PCG64(1))
+    extra = []
+    for hub in (3, 7):                                   # two primary inputs that drive 80 gates each
+        extra.append(np.stack([np.full(80, hub), rng.choice(later, size=80, replace=False)]))
+    ei = np.unique(np.concatenate([ei] + extra, axis=1), axis=1)
+    xcls = torch.from_numpy(a['x'][:, 1].astype('uint8'))
+    old = GraphPlan.QUOTIENT_FRACTION
+    GraphPlan.QUOTIENT_FRACTION = 1.5
+    try:
+        host = GraphPlan(torch.from_numpy(ei), n).quotient(xcls, 3)
+        dev = GraphPlan(torch.from_numpy(ei).cuda(), n).quotient(xcls.cuda(), 3)
+    finally:
+        GraphPlan.QUOTIENT_FRACTION = old
+    assert len(host) == len(dev) >= 2
+    for h, d in zip(host, dev):
+        assert h['C'] == d['C']
+        pairs = set(zip(h['cid'].tolist(), d['cid'].cpu().tolist()))
+        assert len(pairs) == h['C']                      # one-to-one: the same partition (numbering may differ)
