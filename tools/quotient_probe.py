@@ -1,4 +1,5 @@
-"""Where does GraphPlan.quotient spend its time (config 2)?  torch profiler over one warm build."""
+"""Where does GraphPlan.quotient (colour refinement for the quotient stages) spend its time at config 2?  torch profiler over one warm build.
+  python tools/quotient_probe.py"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'multi-gate-vae_amd'))
 import torch
