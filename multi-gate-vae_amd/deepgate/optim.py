@@ -30,7 +30,7 @@ class FlatAdam(torch.optim.Optimizer):
             return False
         base = self._flat['param'].data_ptr()
         for p, off in zip(self._params(), self._flat['offsets']):
-            if p.data_ptr() != base + 4 * off or p.grad is None or p.grad.data_ptr() != self._flat['grad'].data_ptr() + 4 * off:
+            if p.data_ptr() != base + 4 * off:
                 return False
         return True
 
@@ -68,11 +68,28 @@ class FlatAdam(torch.optim.Optimizer):
             self._flatten()
         return self._flat
 
-    def zero_grad(self, set_to_none=False):
-        if self._is_flat():
-            self._flat['grad'].zero_()
-        else:
-            super().zero_grad(set_to_none=False)
+    def zero_grad(self, set_to_none=True):
+        """Gradients are dropped, not zeroed: autograd then ASSIGNS every parameter's gradient instead of adding it to a zero-filled
+        view (one small add kernel per parameter and step, 75 at the BASELINE models); `reduce_gradients` gathers them into the
+        flat buffer with one multi-tensor copy."""
+        for p in self.param_groups[0]['params']:
+            p.grad = None
+
+    def _gather_grads(self):
+        """The parameters' gradients -> their slots of the flat buffer (parameters without a gradient: zeros)."""
+        f = self._flat
+        src, dst, dead = [], [], []
+        for p, off in zip(self._params(), f['offsets']):
+            view = f['grad'][off:off + p.numel()].view(p.shape)
+            if p.grad is None:
+                dead.append(view)
+            elif p.grad.data_ptr() != view.data_ptr():
+                src.append(p.grad)
+                dst.append(view)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if dead:
+            torch._foreach_zero_(dead)
 
     @torch.no_grad()
     def reduce_gradients(self):
@@ -80,6 +97,7 @@ class FlatAdam(torch.optim.Optimizer):
         GPUs, gloo in the CPU tests); returns the factor that turns the sum into the mean."""
         if not self._is_flat():
             self._flatten()
+        self._gather_grads()
         if self.sync_grads and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self._flat['grad'], op=dist.ReduceOp.SUM)
             return 1.0 / dist.get_world_size()

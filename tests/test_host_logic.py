@@ -125,8 +125,12 @@ def test_flat_adam_views_and_checkpoint_format():
     assert m.weight.data_ptr() == f['param'].data_ptr() and m.weight.grad.data_ptr() == f['grad'].data_ptr()
     m(torch.ones(2, 5)).sum().backward()
     assert float(f['grad'].abs().sum()) > 0           # autograd accumulated into the flat buffer
-    opt.zero_grad()
-    assert float(f['grad'].abs().sum()) == 0
+    opt.zero_grad()                                   # gradients are dropped: autograd assigns the next ones (no per-parameter add)
+    assert m.weight.grad is None and m.bias.grad is None
+    m(torch.ones(2, 5)).sum().backward()
+    f['grad'].zero_()
+    assert opt.reduce_gradients() == 1.0              # gathers them into the flat buffer with one multi-tensor copy (no process group: factor 1)
+    assert torch.equal(f['grad'][:15].view(3, 5), m.weight.grad) and float(f['grad'].abs().sum()) > 0
     sd = opt.state_dict()
     ref = torch.optim.Adam(torch.nn.Linear(5, 3).parameters(), lr=1e-3).state_dict()
     assert set(ref['param_groups'][0]) <= set(sd['param_groups'][0]) | {'decoupled_weight_decay'}
