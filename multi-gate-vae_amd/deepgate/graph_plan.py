@@ -240,6 +240,8 @@ class GraphPlan:
 
     QUOTIENT_FRACTION = float(os.environ.get('MGV_QUOTIENT_FRACTION', '3'))      # a half round runs on distinct rows only while they are at most N / 3
 
+    QUOTIENT_MIN_NODES = int(os.environ.get('MGV_QUOTIENT_MIN_NODES', '16384'))   # below: a step is launch-bound, the extra small launches cost more than the rows save
+
     def quotient(self, xcls, max_stages):
         """Quotient stages of the structural encoder.  Every node starts from the same state (ones, digae_layer.py:260), so after
         half round t a node's row depends only on its colour: (feature class, colour after t-1, multiset of its neighbours' colours
@@ -263,7 +265,7 @@ class GraphPlan:
         N, dev = self.N, self.device
         stages = []
         self._check_status()                 # (edge ids outside [0, N) raise here, before the lists are read)
-        if N > 0 and self.E > 0:
+        if N >= self.QUOTIENT_MIN_NODES and self.E > 0:
             i64 = dict(dtype=torch.int64, device=dev)
             gen = torch.Generator(device=dev)
             gen.manual_seed(0x5EED5)

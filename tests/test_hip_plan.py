@@ -250,13 +250,13 @@ def test_device_colour_refinement_equals_the_host_one():
         extra.append(np.stack([np.full(80, hub), rng.choice(later, size=80, replace=False)]))
     ei = np.unique(np.concatenate([ei] + extra, axis=1), axis=1)
     xcls = torch.from_numpy(a['x'][:, 1].astype('uint8'))
-    old = GraphPlan.QUOTIENT_FRACTION
-    GraphPlan.QUOTIENT_FRACTION = 1.5
+    old = GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES
+    GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES = 1.5, 1
     try:
         host = GraphPlan(torch.from_numpy(ei), n).quotient(xcls, 3)
         dev = GraphPlan(torch.from_numpy(ei).cuda(), n).quotient(xcls.cuda(), 3)
     finally:
-        GraphPlan.QUOTIENT_FRACTION = old
+        GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES = old
     assert len(host) == len(dev) >= 2
     for h, d in zip(host, dev):
         assert h['C'] == d['C']

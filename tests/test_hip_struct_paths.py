@@ -108,12 +108,20 @@ def test_quotient_stages_equal_the_per_node_stages(ctype, H):
     from deepgate.graph_plan import GraphPlan
     arrays = syn.collate([syn.make_graph(ctype, 512 + 120 * 60, 60, 900 + i, n_inputs=512) for i in range(3)])
     n = arrays['num_nodes']
+    # two nets with hundreds of consumers (a primary input and a level-1 gate): singleton colours whose representative rows take
+    # the heavy-row pre-pass inside the quotient stages
+    rng = np.random.Generator(np.random.PCG64(8))
+    lv = arrays['forward_level']
+    hub2 = int(np.nonzero(lv == 1)[0][2])
+    extra = [np.stack([np.full(400, 5), rng.choice(np.nonzero(lv > 0)[0], size=400, replace=False)]),
+             np.stack([np.full(300, hub2), rng.choice(np.nonzero(lv >= 2)[0], size=300, replace=False)])]
+    arrays['edge_index'] = np.unique(np.concatenate([arrays['edge_index']] + extra, axis=1), axis=1)
     ei = torch.from_numpy(arrays['edge_index']).to(dev)
     x = torch.from_numpy(arrays['x']).to(dev)
     plan = GraphPlan(ei, n)
     xcls = x[:, 1].to(torch.uint8).contiguous()
     quot = plan.quotient(xcls, 4)
-    assert len(quot) >= 2 and quot[0]['C'] <= 8, [s['C'] for s in quot]
+    assert len(quot) >= 2 and quot[0]['C'] <= 16 and max(s['heavy'][0] for s in quot) >= 1, [(s['C'], s['heavy'][0]) for s in quot]
     res = {}
     for flag in (True, False):
         old = ops.QUOTIENT

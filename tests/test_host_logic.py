@@ -284,12 +284,12 @@ def test_quotient_colours_equal_brute_force_refinement(ctype):
     N, ei = a['num_nodes'], a['edge_index']
     plan = GraphPlan(torch.from_numpy(ei), N)
     xcls = torch.from_numpy(a['x'][:, 1].astype('uint8'))
-    old = GraphPlan.QUOTIENT_FRACTION
-    GraphPlan.QUOTIENT_FRACTION = 1.5                      # small graphs: let three half rounds qualify
+    old = GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES
+    GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES = 1.5, 1      # small graphs: let three half rounds qualify
     try:
         q = plan.quotient(xcls, 3)
     finally:
-        GraphPlan.QUOTIENT_FRACTION = old
+        GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES = old
     assert len(q) >= 2
     col = [0] * N
     for t, s in enumerate(q, start=1):
