@@ -18,7 +18,7 @@
 //     bit-identical from run to run.
 #include "struct_stage_x3_common.h"
 #ifndef MGV_BWD2_D
-#define MGV_BWD2_D 2
+#define MGV_BWD2_D 3            // neighbour slots per row and gather round (2 x 3 x 2 row loads in flight per lane; 2: 1-2 % slower, same box)
 #endif
 #ifndef MGV_ABL
 #define MGV_ABL 0            // timing ablations of diagnostic builds (results are wrong): 1 no MFMA, 2 light VALU in P2/P3, 4 no row gathers, 8 no output stores, 16 dgrad weights loaded once, 32 (with 1) no LDS fragment reads
