@@ -312,13 +312,15 @@ int mgv_recon_heavy_lists(int H, const float* s, const float* t, int ld, int64_t
                           const int32_t* seg_e1, const int32_t* list, int which, float* partial_ws, float* out, void* stream);
 /* negative sampling of the reconstruction loss (dg_ae_model_aig.py:115-119, torch_geometric negative_sampling): E pairs
  * uniform over {(u, v): u != v, (u, v) not an edge of the CSR}, from a counter-based generator (seed); cnt_out/cnt_in
- * [N] (zeroed by the caller) receive the pairs' per-source / per-destination counts.  mgv_neg_bucket then buckets the
- * pairs: out_ptr/in_ptr = exclusive scans of the counts ([N+1]), cur_* = zeroed [N] cursors; outputs the pairs
- * grouped by source (srt_src, srt_dst: int64 like edge_index rows), out_dst[E] and in_src[E] (int32 CSR payloads). */
+ * [N] (zeroed by the caller) receive the pairs' per-source / per-destination counts, rank_out/rank_in [E] each pair's place inside
+ * its source's / destination's bucket (the count it found).  mgv_neg_bucket then buckets the pairs without atomics: out_ptr/in_ptr =
+ * exclusive scans of the counts ([N+1]); outputs the pairs grouped by source (srt_src, srt_dst: int64 like edge_index rows),
+ * out_dst[E] and in_src[E] (int32 CSR payloads; order inside a bucket = thread arrival: mgv_sort_lists_i32 fixes it). */
 int mgv_neg_sample(int64_t N, int64_t E, uint64_t seed, const int32_t* pos_out_ptr, const int32_t* pos_out_dst,
-                   int64_t* neg_src, int64_t* neg_dst, int32_t* cnt_out, int32_t* cnt_in, void* stream);
+                   int64_t* neg_src, int64_t* neg_dst, int32_t* cnt_out, int32_t* cnt_in, int32_t* rank_out, int32_t* rank_in,
+                   void* stream);
 int mgv_neg_bucket(int64_t E, const int64_t* neg_src, const int64_t* neg_dst, const int32_t* out_ptr, const int32_t* in_ptr,
-                   int32_t* cur_out, int32_t* cur_in, int64_t* srt_src, int64_t* srt_dst, int32_t* out_dst, int32_t* in_src,
+                   const int32_t* rank_out, const int32_t* rank_in, int64_t* srt_src, int64_t* srt_dst, int32_t* out_dst, int32_t* in_src,
                    void* stream);
 
 /* ---- functional-similarity loss (trainer.py:158-163, utils/utils.py:32-36): dis = 1 - cos(hf[a], hf[b]),
@@ -393,8 +395,8 @@ int mgv_plan_csr_scratch_ints(int64_t N, int64_t E);                            
 int mgv_plan_csr(int64_t N, int64_t E, const int64_t* src, const int64_t* dst, int32_t* in_ptr, int32_t* in_src, int32_t* in_dst,
                  int32_t* out_ptr, int32_t* out_dst, int32_t* out_slot, int32_t* in_eid /* NULL or [E]: edge id per in-CSR slot */,
                  int32_t* out_eid /* NULL or [E] */, int32_t* scratch, int64_t scratch_ints, int32_t* status, void* stream);
-/* every list vals[ptr[n] .. ptr[n+1]) ascending, in place; scratch: N + 1 + E ints.  Applied to the lists mgv_neg_bucket fills through
- * atomic cursors: their order then no longer depends on thread arrival (equal values are interchangeable) */
+/* every list vals[ptr[n] .. ptr[n+1]) ascending, in place; scratch: N + 1 + E ints.  Applied to the lists mgv_neg_bucket fills in
+ * thread-arrival order: their order then no longer depends on it (equal values are interchangeable) */
 int mgv_sort_lists_i32(int64_t N, int64_t E, const int32_t* ptr, int32_t* vals, int32_t* scratch, int64_t scratch_ints, void* stream);
 /* ASAP levels by frontier relaxation over the out-CSR; `rounds` level steps are enqueued; done[0] == N afterwards iff complete.
  * scratch: 3 N + rounds + 2 ints */

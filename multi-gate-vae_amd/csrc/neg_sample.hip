@@ -19,7 +19,8 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 }
 
 __global__ __launch_bounds__(kThreads) void k_neg_sample(int64_t N, int64_t E, uint64_t seed, const int32_t* out_ptr, const int32_t* out_dst,
-                                                        int64_t* neg_src, int64_t* neg_dst, int32_t* cnt_out, int32_t* cnt_in) {
+                                                        int64_t* neg_src, int64_t* neg_dst, int32_t* cnt_out, int32_t* cnt_in,
+                                                        int32_t* rank_out, int32_t* rank_in) {
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < E; i += (int64_t)gridDim.x * kThreads) {
         uint64_t ctr = seed ^ ((uint64_t)i * 0xD1342543DE82EF95ull);
         int s, d;
@@ -34,42 +35,43 @@ __global__ __launch_bounds__(kThreads) void k_neg_sample(int64_t N, int64_t E, u
             if (ok || attempt >= 64) break;      // 64 straight rejections: the graph is (nearly) complete; keep the pair
         }
         neg_src[i] = s; neg_dst[i] = d;
-        atomicAdd(cnt_out + s, 1);
-        atomicAdd(cnt_in + d, 1);
+        // the pair's place inside its source's and its destination's bucket: the count it found (the bucket pass then needs no atomics)
+        rank_out[i] = atomicAdd(cnt_out + s, 1);
+        rank_in[i] = atomicAdd(cnt_in + d, 1);
     }
 }
 
-// bucket pass: ptr arrays = exclusive scans of the counts, cur_* = zeroed cursors
+// bucket pass: ptr arrays = exclusive scans of the counts, rank_* = the pairs' places inside their buckets (from the sampling pass)
 __global__ __launch_bounds__(kThreads) void k_neg_bucket(int64_t E, const int64_t* neg_src, const int64_t* neg_dst, const int32_t* out_ptr,
-                                                        const int32_t* in_ptr, int32_t* cur_out, int32_t* cur_in, int64_t* srt_src,
+                                                        const int32_t* in_ptr, const int32_t* rank_out, const int32_t* rank_in, int64_t* srt_src,
                                                         int64_t* srt_dst, int32_t* out_dst, int32_t* in_src) {
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < E; i += (int64_t)gridDim.x * kThreads) {
         const int s = (int)neg_src[i], d = (int)neg_dst[i];
-        const int p = out_ptr[s] + atomicAdd(cur_out + s, 1);
+        const int p = out_ptr[s] + rank_out[i];
         srt_src[p] = s; srt_dst[p] = d; out_dst[p] = d;
-        const int q = in_ptr[d] + atomicAdd(cur_in + d, 1);
-        in_src[q] = s;
+        in_src[in_ptr[d] + rank_in[i]] = s;
     }
 }
 
 }  // namespace mgv
 
 extern "C" int mgv_neg_sample(int64_t N, int64_t E, uint64_t seed, const int32_t* pos_out_ptr, const int32_t* pos_out_dst,
-                              int64_t* neg_src, int64_t* neg_dst, int32_t* cnt_out, int32_t* cnt_in, void* stream) {
-    MGV_CHECK_ARG(N >= 2 && N < (1ll << 31) && E >= 0 && pos_out_ptr && neg_src && neg_dst && cnt_out && cnt_in);
+                              int64_t* neg_src, int64_t* neg_dst, int32_t* cnt_out, int32_t* cnt_in, int32_t* rank_out, int32_t* rank_in,
+                              void* stream) {
+    MGV_CHECK_ARG(N >= 2 && N < (1ll << 31) && E >= 0 && pos_out_ptr && neg_src && neg_dst && cnt_out && cnt_in && rank_out && rank_in);
     if (E == 0) return MGV_OK;
     hipLaunchKernelGGL(mgv::k_neg_sample, dim3(mgv::grid_for((E + mgv::kThreads - 1) / mgv::kThreads, 16)), dim3(mgv::kThreads), 0,
-                       static_cast<hipStream_t>(stream), N, E, seed, pos_out_ptr, pos_out_dst, neg_src, neg_dst, cnt_out, cnt_in);
+                       static_cast<hipStream_t>(stream), N, E, seed, pos_out_ptr, pos_out_dst, neg_src, neg_dst, cnt_out, cnt_in, rank_out, rank_in);
     MGV_LAUNCH_RET();
 }
 
 extern "C" int mgv_neg_bucket(int64_t E, const int64_t* neg_src, const int64_t* neg_dst, const int32_t* out_ptr, const int32_t* in_ptr,
-                              int32_t* cur_out, int32_t* cur_in, int64_t* srt_src, int64_t* srt_dst, int32_t* out_dst, int32_t* in_src,
+                              const int32_t* rank_out, const int32_t* rank_in, int64_t* srt_src, int64_t* srt_dst, int32_t* out_dst, int32_t* in_src,
                               void* stream) {
-    MGV_CHECK_ARG(E >= 0 && out_ptr && in_ptr && cur_out && cur_in);
+    MGV_CHECK_ARG(E >= 0 && out_ptr && in_ptr && rank_out && rank_in);
     if (E == 0) return MGV_OK;
     MGV_CHECK_ARG(neg_src && neg_dst && srt_src && srt_dst && out_dst && in_src);
     hipLaunchKernelGGL(mgv::k_neg_bucket, dim3(mgv::grid_for((E + mgv::kThreads - 1) / mgv::kThreads, 16)), dim3(mgv::kThreads), 0,
-                       static_cast<hipStream_t>(stream), E, neg_src, neg_dst, out_ptr, in_ptr, cur_out, cur_in, srt_src, srt_dst, out_dst, in_src);
+                       static_cast<hipStream_t>(stream), E, neg_src, neg_dst, out_ptr, in_ptr, rank_out, rank_in, srt_src, srt_dst, out_dst, in_src);
     MGV_LAUNCH_RET();
 }

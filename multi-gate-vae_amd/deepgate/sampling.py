@@ -62,18 +62,20 @@ def negative_sampling_device(plan, num_neg_samples=None, generator=None):
     E = (plan.E - plan.num_self_loops) + N if num_neg_samples is None else int(num_neg_samples)
     base = generator.initial_seed() if generator is not None else torch.initial_seed()
     seed = (base * 0x9E3779B97F4A7C15 + next(_CALLS) * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
-    scratch = torch.zeros(4, N, dtype=torch.int32, device=dev)          # counts by source / destination, bucket cursors
+    scratch = torch.zeros(2, N, dtype=torch.int32, device=dev)          # counts by source / destination
     neg = torch.empty(2, E, dtype=torch.int64, device=dev)
-    _hip.call('mgv_neg_sample', N, E, seed, ptr(plan.out_ptr), ptr(plan.out_dst), ptr(neg[0]), ptr(neg[1]), ptr(scratch[0]), ptr(scratch[1]))
+    rank = torch.empty(2, max(E, 1), dtype=torch.int32, device=dev)     # every pair's place inside its two buckets
+    _hip.call('mgv_neg_sample', N, E, seed, ptr(plan.out_ptr), ptr(plan.out_dst), ptr(neg[0]), ptr(neg[1]), ptr(scratch[0]), ptr(scratch[1]),
+              ptr(rank[0]), ptr(rank[1]))
     ptrs = torch.zeros(2, N + 1, dtype=torch.int32, device=dev)
     for k in range(2):                 # 1-D scans (the device-wide scan; the batched innermost-dim kernel is ~100x slower here)
         ptrs[k, 1:] = torch.cumsum(scratch[k], 0, dtype=torch.int32)
     srt = torch.empty(2, E, dtype=torch.int64, device=dev)
     out_dst = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     in_src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-    _hip.call('mgv_neg_bucket', E, ptr(neg[0]), ptr(neg[1]), ptr(ptrs[0]), ptr(ptrs[1]), ptr(scratch[2]), ptr(scratch[3]),
+    _hip.call('mgv_neg_bucket', E, ptr(neg[0]), ptr(neg[1]), ptr(ptrs[0]), ptr(ptrs[1]), ptr(rank[0]), ptr(rank[1]),
               ptr(srt[0]), ptr(srt[1]), ptr(out_dst), ptr(in_src))
-    # the buckets were filled through atomic cursors: sort every list by neighbour id so that the order (and with it every
+    # the buckets were filled in thread-arrival order: sort every list by neighbour id so that the order (and with it every
     # floating-point sum over a list) no longer depends on thread arrival; equal ids are duplicates of one pair
     ss = torch.empty(N + 1 + E, dtype=torch.int32, device=dev)
     _hip.call('mgv_sort_lists_i32', N, E, ptr(ptrs[0]), ptr(out_dst), ptr(ss), ss.numel())
