@@ -262,3 +262,30 @@ def test_device_colour_refinement_equals_the_host_one():
         assert h['C'] == d['C']
         pairs = set(zip(h['cid'].tolist(), d['cid'].cpu().tolist()))
         assert len(pairs) == h['C']                      # one-to-one: the same partition (numbering may differ)
+
+
+@pytest.mark.gpu
+def test_colour_check_rejects_a_wrong_grouping():
+    """mgv_colour_check is what makes the quotient stages exact: a grouping that merges nodes with different neighbour-colour
+    multisets (what a collision of the 64-bit grouping key would produce) must be flagged; the true grouping must pass."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from deepgate import _hip
+    from deepgate._hip import ptr
+    from deepgate.graph_plan import GraphPlan
+    dev = torch.device('cuda:0')
+    # nodes 0..3 inputs with colours 0,0,1,1; nodes 4..7: 4 <- {0,2}, 5 <- {1,3} (same multiset {0,1}), 6 <- {0,1} ({0,0}), 7 <- {2,3} ({1,1})
+    ei = torch.tensor([[0, 2, 1, 3, 0, 1, 2, 3], [4, 4, 5, 5, 6, 6, 7, 7]], device=dev)
+    plan = GraphPlan(ei, 8)
+    prev = torch.tensor([0, 0, 1, 1, 2, 2, 2, 2], dtype=torch.int32, device=dev)
+    xcls = torch.zeros(8, dtype=torch.uint8, device=dev)
+
+    def check(cid, rep):
+        flags = torch.zeros(2, dtype=torch.int32, device=dev)
+        cid_t, rep_t = torch.tensor(cid, device=dev), torch.tensor(rep, device=dev)      # (kept alive across the launch)
+        _hip.call('mgv_colour_check', 8, ptr(plan.in_ptr), ptr(plan.in_src), ptr(prev), ptr(xcls), ptr(cid_t), ptr(rep_t), ptr(flags))
+        return flags.tolist()
+    good = ([0, 0, 1, 1, 2, 2, 3, 4], [0, 2, 4, 6, 7])            # 4 and 5 share a colour, 6 and 7 have their own
+    assert check(*good) == [0, 0]
+    assert check([0, 0, 1, 1, 2, 2, 2, 3], [0, 2, 4, 7])[0] == 1   # 6 ({0,0}) merged with 4 ({0,1}): same degree, another multiset
+    assert check([0, 0, 0, 1, 2, 2, 3, 4], [0, 3, 4, 6, 7])[0] == 1   # node 2 (previous colour 1) merged with nodes of previous colour 0
