@@ -294,13 +294,19 @@ class GraphPlan:
                     h1 = torch.zeros(N, **i64).index_add_(0, owner, f[0][pn])
                     h2 = torch.zeros(N, **i64).index_add_(0, owner, f[1][pn])
                     mix = h1 * 0x1E3779B97F4A7C15 + h2 + f[2][prev] + xc * 0x632BE59BD9B4E019 + deg * 0x2545F4914F6CDD1D
-                uniq, inv, members = torch.unique(mix, return_inverse=True, return_counts=True)
-                C = int(uniq.numel())
+                # ONE stable sort of the keys groups the nodes: colour = rank of the key, representative = first member of its run
+                # (a scatter-min onto a handful of addresses costs 27 ms; torch.unique + a second sort by colour 1.6 ms more)
+                skey, by_colour = torch.sort(mix, stable=True)
+                first = torch.ones(N, dtype=torch.bool, device=dev)
+                first[1:] = skey[1:] != skey[:-1]
+                starts = torch.nonzero(first).reshape(-1)
+                C = int(starts.numel())
                 if C * self.QUOTIENT_FRACTION > N:
                     break
-                # representative = first member (stable sort by colour; a scatter-min onto a handful of addresses costs 27 ms)
-                by_colour = torch.sort(inv, stable=True).indices
-                rep = by_colour[torch.cumsum(members, 0) - members]
+                inv = torch.empty(N, **i64)
+                inv[by_colour] = torch.cumsum(first, 0) - 1
+                members = torch.diff(starts, append=torch.tensor([N], **i64))
+                rep = by_colour[starts]
                 # exact check of the grouping (the key above only PROPOSES it): every member has its representative's feature class,
                 # previous colour, degree and neighbour-colour multiset
                 n_long = 1
