@@ -645,8 +645,8 @@ extern "C" int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, con
     MGV_CHECK_ARG(table_own_idx == nullptr || N < (1 << 24));
     if (table_own_idx) { a.hshift = 24; a.gmask = 0xffffff; a.own_idx = table_own_idx; }
     MGV_SET_STAMPS2(a);
-    { static const int v = [] { const char* e = getenv("MGV_XCD_TILES"); return (e && e[0] == '0') ? 0 : 1; }(); a.xcd = v; }
-    { static const int v = [] { const char* e = getenv("MGV_ROW_PREFETCH"); return (e && e[0] == '0') ? 0 : 1; }(); a.prefetch = v; }
+    a.xcd = 1;           // XCD-contiguous tile order and the L2 row prefetch: both measured, no switch left
+    a.prefetch = 1;
     MGV_CHECK_ARG(heavy_n >= 0 && (heavy_n == 0 || (heavy_nodes && heavy_ws)));
     mgv::launch_heavy_sums<64>(a, heavy_n, heavy_nodes, heavy_ws, gy_agg != nullptr, static_cast<hipStream_t>(stream));
     return mgv::launch_bwd2_x3(a, workspace, workspace_floats, static_cast<hipStream_t>(stream));

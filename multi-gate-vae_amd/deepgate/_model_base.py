@@ -3,8 +3,6 @@
 per-gate-type attention + GRU sweep -> (hs, hf); readout, reconstruction loss, checkpoint loading.
 Sub-module names and construction order follow the reference so state_dicts and seeded
 initialisation line up."""
-import os
-
 import torch
 from torch import nn
 
@@ -16,7 +14,7 @@ from .digae_layer import DirectedInnerProductDecoder
 from .sampling import NegativeEdges, negative_sampling, negative_sampling_device
 
 EPS = 1e-15
-DEVICE_SAMPLER = os.environ.get('MGV_NEG_SAMPLER', 'device') != 'torch'
+DEVICE_SAMPLER = True             # fused device sampler whenever the batch has a plan (the torch rejection sampler serves callers without one)
 MAX_LOGSTD = 10
 
 

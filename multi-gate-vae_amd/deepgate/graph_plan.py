@@ -238,9 +238,9 @@ class GraphPlan:
         self._stage1 = (key, out)
         return out
 
-    QUOTIENT_FRACTION = float(os.environ.get('MGV_QUOTIENT_FRACTION', '3'))      # a half round runs on distinct rows only while they are at most N / 3
+    QUOTIENT_FRACTION = 3.0    # a half round runs on distinct rows only while they are at most N / 3 (measured: DESIGN.md 4.3)
 
-    QUOTIENT_MIN_NODES = int(os.environ.get('MGV_QUOTIENT_MIN_NODES', '16384'))   # below: a step is launch-bound, the extra small launches cost more than the rows save
+    QUOTIENT_MIN_NODES = 16384   # below: a step is launch-bound, the extra small launches cost more than the rows save
 
     def quotient(self, xcls, max_stages):
         """Quotient stages of the structural encoder.  Every node starts from the same state (ones, digae_layer.py:260), so after

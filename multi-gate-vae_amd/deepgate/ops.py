@@ -20,7 +20,7 @@ LN_EPS = 1e-5
 # fp32 MFMA.  Hidden widths the x3 kernels do not cover (H=16) always run in fp32.
 PRECISION = os.environ.get('MGV_PRECISION', 'x3')
 # first half round of an encoder from one kernel row per (degree, class) pair ('table') or over all nodes ('full')
-FIRST_STAGE_TABLE = os.environ.get('MGV_FIRST_STAGE', 'table') != 'full'
+FIRST_STAGE_TABLE = True          # first half round per (degree, class) pair / quotient stages (tests switch it off to compare with the per-node launch)
 
 
 def use_x3(H):
@@ -126,7 +126,7 @@ def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
 # The bf16x3 half-round backward at H = 64 is struct_stage_bwd2_x3.hip (register-resident recompute weights, transposed products,
 # slab-reduced deterministic parameter gradients); the first kernel (struct_stage_x3.hip) serves H = 32 only (tools/bench_stage.py
 # still times both through the C ABI).
-TABLE_MODE = os.environ.get('MGV_TABLE_MODE', '1') != '0'     # half round 2 of an encoder reads the (degree, class) table directly
+TABLE_MODE = True                 # half round 2 of an encoder reads the (degree, class) table directly
 QUOTIENT = os.environ.get('MGV_QUOTIENT', '1') != '0'         # early half rounds on one row per colour (GraphPlan.quotient)
 _WS = {}
 
@@ -390,7 +390,7 @@ _LIN_X3 = {}
 
 def _lin_x3(M, K):
     """Layer shapes served by the bf16x3 linear kernels (the others stay on the fp32 MFMA ones)."""
-    if PRECISION != 'x3' or os.environ.get('MGV_LIN_X3', '1') == '0':
+    if PRECISION != 'x3':
         return False
     key = (int(M), int(K))
     if key not in _LIN_X3:

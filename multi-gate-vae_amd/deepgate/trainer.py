@@ -112,7 +112,7 @@ class Trainer():
             for b in self.model.buffers():
                 torch.distributed.broadcast(b.data, 0)
         self.model_epoch = 0
-        self.overlap = os.environ.get('MGV_OVERLAP', '1') != '0'     # second stream for the reconstruction branch
+        self.overlap = True          # second stream for the reconstruction branch
         self._side = None
         if self.local_rank == 0:
             self.logger = Logger(self.log_path)
