@@ -192,6 +192,10 @@ def roofline_record(summ, table, N, E, H, step_s):
             roof['valu_busy'] = kern.get('valu_busy')
             if kern.get('coexec_share') is not None:
                 roof['valu_mfma_coexec_share'] = kern.get('coexec_share')
+            if kern.get('mfma_busy') is not None and kern.get('valu_busy') is not None:
+                # matrix and vector instructions of a SIMD's waves take turns on this part (tools/micro/coexec.hip,
+                # profiles/r03_coexec_micro.txt): the two busy shares add up to the SIMDs' issue occupancy
+                roof['simd_issue_share'] = kern['mfma_busy'] + kern['valu_busy']
             roof['mfma_source'] = 'profiles/%s: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), rocprofv3 --pmc' % fname
     return roof, order
 
