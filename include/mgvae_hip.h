@@ -65,11 +65,15 @@ int mgv_struct_stage_bwd(int H, int64_t N, const float* h_in, const int32_t* nbr
  * with one workgroup per node instead of by one lane group inside the tile kernel (100,000 consumers: 38 ms per launch there).
  * table_own_idx (NULL = off): TABLE MODE for the half round that follows the (degree, class)-table one — h_in is the C-row table,
  * a node's own row is h_in[table_own_idx[node]], every nbr_idx entry carries its neighbour's table row in the top byte
- * (entry = node | row << 24, N < 2^24): the N x H expansion of the table is never gathered. */
+ * (entry = node | row << 24, N < 2^24): the N x H expansion of the table is never gathered.
+ * ln_stats_out (forward) / ln_stats (bwd2) [N][2], NULL = off: {mean, rstd} of every row's pre-LayerNorm state, kept by the forward
+ * so that the backward's recompute needs two cross-lane row sums instead of four and no four-way combination of the column waves'
+ * partial statistics (-3 % per backward launch); ignored when ln_w is NULL. */
 int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
                             const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
                             const float* bhh, const float* ln_w, const float* ln_b, float ln_eps, float* h_out,
-                            int heavy_n, const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx, void* stream);
+                            int heavy_n, const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx,
+                            float* ln_stats_out, void* stream);
 int mgv_struct_stage_bwd_x3(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
                             const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
                             const float* bhh, const float* ln_w, const float* ln_b, float ln_eps,
@@ -90,7 +94,8 @@ int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, const int32_t*
                              const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
                              float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
                              float* dln_b, float* workspace, int64_t workspace_floats, int heavy_n,
-                             const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx, void* stream);
+                             const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx,
+                             const float* ln_stats, void* stream);
 
 /* ---- Linear over node rows (hs_linear dg_ae_model_aig.py:64, hs_decompose :109, fc_{s,t}_{mu,logstd}
  * digvae_model.py:135-136, readout Linear layers mlp.py:29,38; also the dgrad with W^T):

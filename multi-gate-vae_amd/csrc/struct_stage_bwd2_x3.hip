@@ -53,7 +53,8 @@ struct B2 {
     static constexpr int IDX_BYTES = 2 * kIdxStride * 4;
     static constexpr int o_xe = o_idx + IDX_BYTES;            // xe_hi, xe_lo [64][XLD]
     static constexpr int o_lnacc = o_xe + 2 * kTileRows * XLD * 2;    // per-wave LayerNorm affine gradient sums [8 waves][2][16 columns]
-    static constexpr int bytes = o_lnacc + kNW * 2 * 16 * 4;
+    static constexpr int o_stat = o_lnacc + kNW * 2 * 16 * 4;     // {mean, rstd} of the tile's rows when the forward kept them (StageX3Args::ln_stats)
+    static constexpr int bytes = o_stat + kTileRows * 2 * 4;
     static_assert(bytes <= 160 * 1024, "LDS budget");
     // per-workgroup gradient slab (floats): [8 waves][14 float4 slots][64 lanes] then dlnw[64], dlnb[64]
     static constexpr int SLOTS = 14;                          // 12 weight-gradient tiles, 2 bias-type tiles
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
     __bf16* xe_hi = reinterpret_cast<__bf16*>(smem_raw + B2::o_xe);
     __bf16* xe_lo = xe_hi + kTileRows * XLD;
     float* s_lnacc = reinterpret_cast<float*>(smem_raw + B2::o_lnacc);
+    float* s_stat = reinterpret_cast<float*>(smem_raw + B2::o_stat);
 
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wc = w & 3, m = w >> 2;     // wave-uniform: scalar registers
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
     const int lane = t_ & 63, r = lane & 15, q = lane >> 4, grp = t_ >> 4, lr = t_ & 15, c0 = 16 * wc + 4 * q; \
     (void)lane; (void)r; (void)q; (void)grp; (void)lr; (void)c0;
     const bool has_ln = a.lnw != nullptr;
+    const bool has_stats = has_ln && a.ln_stats != nullptr;
     const bool need_dgrad = a.g_direct_out != nullptr;
     const float ln_eps = a.eps;
     const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
@@ -176,6 +179,14 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             float4 acc[2], own[2], dy[2];
             float deg[2];
             int cls[2];
+            float st_r[2] = {0.f, 0.f};          // the rows' kept LayerNorm statistics: requested with the row loads, parked behind barrier (0)
+            if (has_stats && lr < 2) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int64_t node = base + grp + rr * 32;
+                    if (node < a.N) st_r[rr] = a.ln_stats[node * 2 + lr];
+                }
+            }
 #if MGV_ABL & 4
             for (int rr = 0; rr < 2; ++rr) { acc[rr] = make_float4(0.1f * lr, 0.2f, 0.3f, 0.4f); own[rr] = acc[rr]; dy[rr] = acc[rr]; deg[rr] = 2.f; cls[rr] = 1; }
 #else
@@ -194,6 +205,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                 st_bf4(hin_hi + row * LDP + 4 * lr, hi); st_bf4(hin_lo + row * LDP + 4 * lr, lo);
                 st4(s_dy + row * LDF + 4 * lr, dy[rr]);
                 if (lr == 0) { sv.deg[row] = deg[rr]; sv.cls[row] = cls[rr]; }
+                if (has_stats && lr < 2) s_stat[row * 2 + lr] = st_r[rr];
                 const float xe = lr == 0 ? deg[rr] : (lr <= 8 ? (cls[rr] == lr - 1 ? 1.0f : 0.0f) : (lr == 9 ? 1.0f : 0.0f));
                 __bf16 xh, xl;
                 split_bf16(xe, xh, xl);
@@ -309,7 +321,18 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             const f32x4 pre = nn + zz * (hp - nn);
             vr[il] = rr; vz[il] = zz; vn[il] = nn; vg[il] = ghn;
             const float s1 = (pre[0] + pre[1]) + (pre[2] + pre[3]);
-            if (has_ln) {
+            if (has_stats) {
+                // mean and rstd come from the forward: the row sums left are the two that depend on dY
+                const float mean = s_stat[row * 2], rstd = s_stat[row * 2 + 1];
+                const f32x4 dy = ldv4(s_dy + row * LDF + c0), gm = ldv4(sv.lnw + c0);
+                const f32x4 xh = (pre - mean) * rstd, gg = dy * gm;
+                const f32x4 gd = gg * xh;
+                vd[il] = xh;
+                const float s3 = quad_rows_sum((gg[0] + gg[1]) + (gg[2] + gg[3]));
+                const float s4 = quad_rows_sum((gd[0] + gd[1]) + (gd[2] + gd[3]));
+                mw[il] = rstd;
+                if (q == 0) s_part[row * 4 + wc] = f32x4{s3, s4, 0.f, 0.f};
+            } else if (has_ln) {
                 const float mean_w = quad_rows_sum(s1) * (1.0f / 16.0f);
                 const f32x4 dy = ldv4(s_dy + row * LDF + c0), gm = ldv4(sv.lnw + c0);
                 const f32x4 d = pre - mean_w, gg = dy * gm;
@@ -352,7 +375,20 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
             const bf16x4 hh = *reinterpret_cast<const bf16x4*>(hin_hi + row * LDP + c0);
             const bf16x4 hl = *reinterpret_cast<const bf16x4*>(hin_lo + row * LDP + c0);
             float dh[4];
-            if (has_ln) {
+            if (has_stats) {
+                const f32x4 p0 = s_part[row * 4 + 0], p1 = s_part[row * 4 + 1], p2 = s_part[row * 4 + 2], p3 = s_part[row * 4 + 3];
+                const float rstd = mw[il];
+                const float c1 = (p0[0] + p1[0] + p2[0] + p3[0]) * (1.0f / H);
+                const float c2 = (p0[1] + p1[1] + p2[1] + p3[1]) * (1.0f / H);
+                const float4 gm = ld4(sv.lnw + c0);
+                const float gm_[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xhat = vd[il][e];
+                    lnw_acc[e] += dy_[e] * xhat; lnb_acc[e] += dy_[e];
+                    dh[e] = rstd * (dy_[e] * gm_[e] - c1 - xhat * c2);
+                }
+            } else if (has_ln) {
                 const f32x4 p0 = s_part[row * 4 + 0], p1 = s_part[row * 4 + 1], p2 = s_part[row * 4 + 2], p3 = s_part[row * 4 + 3];
                 const float mean = (p0[0] + p1[0] + p2[0] + p3[0]) * 0.25f;
                 const float e0 = p0[0] - mean, e1 = p1[0] - mean, e2 = p2[0] - mean, e3 = p3[0] - mean;
@@ -626,7 +662,8 @@ extern "C" int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, con
                                         const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
                                         float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
                                         float* dln_b, float* workspace, int64_t workspace_floats, int heavy_n,
-                                        const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx, void* stream) {
+                                        const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx,
+                                        const float* ln_stats, void* stream) {
     MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && gy_direct);
     MGV_CHECK_ARG(dWc && dbc && dWhh && dbhh && dxtab);
     MGV_CHECK_ARG(C >= 1 && C <= mgv::kMaxClsX3);
@@ -644,6 +681,7 @@ extern "C" int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, con
     a.gmask = -1;
     MGV_CHECK_ARG(table_own_idx == nullptr || N < (1 << 24));
     if (table_own_idx) { a.hshift = 24; a.gmask = 0xffffff; a.own_idx = table_own_idx; }
+    a.ln_stats = ln_w ? const_cast<float*>(ln_stats) : nullptr;
     MGV_SET_STAMPS2(a);
     a.xcd = 1;           // XCD-contiguous tile order and the L2 row prefetch: both measured, no switch left
     a.prefetch = 1;

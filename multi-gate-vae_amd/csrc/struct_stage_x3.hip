@@ -218,6 +218,10 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
                 v = make_float4(v.x - mean, v.y - mean, v.z - mean, v.w - mean);
                 const float var = group_sum<S::LPR>(dot4(v, v)) * (1.0f / H);
                 const float rstd = rsqrtf(var + a.eps);
+                if (a.ln_stats && lr < 2 && node < a.N) {      // kept for the backward (bwd2); buffer store: a 32-bit offset, no address registers
+                    const auto rs = __builtin_amdgcn_make_buffer_rsrc(a.ln_stats, 0, 0xfffffff0u, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lr ? rstd : mean), rs, (unsigned)node * 8u + 4u * lr, 0, 0);
+                }
                 const float4 g = ld4(sv.lnw + 4 * lr), bb = ld4(sv.lnb + 4 * lr);
                 v = make_float4(v.x * rstd * g.x + bb.x, v.y * rstd * g.y + bb.y, v.z * rstd * g.z + bb.z, v.w * rstd * g.w + bb.w);
             }
@@ -676,7 +680,7 @@ extern "C" int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, cons
                                        const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
                                        const float* bhh, const float* ln_w, const float* ln_b, float ln_eps, float* h_out,
                                        int heavy_n, const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx,
-                                       void* stream) {
+                                       float* ln_stats_out, void* stream) {
     MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && h_out && (table_own_idx == nullptr || N < (1 << 24)));
     MGV_CHECK_ARG(heavy_n >= 0 && (heavy_n == 0 || (heavy_nodes && heavy_ws)));
     MGV_CHECK_ARG(C >= 1 && C <= mgv::kMaxClsX3);
@@ -688,6 +692,7 @@ extern "C" int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, cons
     a.wpack = static_cast<const __bf16*>(wpack_bf16); a.bc = bc; a.bhh = bhh; a.lnw = ln_w; a.lnb = ln_b; a.eps = ln_eps; a.h_out = h_out;
     a.gmask = -1;
     if (table_own_idx) { a.hshift = 24; a.gmask = 0xffffff; a.own_idx = table_own_idx; }
+    a.ln_stats = ln_w ? ln_stats_out : nullptr;
     MGV_SET_STAMPS(a);
     a.xcd = xcd_tiles();
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -36,6 +36,9 @@ struct StageX3Args {
     // table mode (the half round after the (degree, class)-table one): h_in is the C-row table, a neighbour entry carries its class in
     // the top byte (h row = entry >> 24, gradient row = entry & 0xffffff), a node's own h row is own_idx[node].  Normal mode: 0 / ~0 / NULL.
     int hshift; int gmask; const int32_t* own_idx;
+    // LayerNorm statistics of the stage's rows, [N][2] = {mean, rstd} of the pre-LayerNorm state: written by the forward kernel, read by
+    // the bwd2 kernel (which then skips two of its four cross-lane row sums and the four-way combination); NULL: not kept / recomputed
+    float* ln_stats;
 };
 
 #include "mgv_stamps.h"

@@ -97,9 +97,11 @@ def _heavy_args(heavy, H, device):
     return n, ptr(nodes), ptr(hw)
 
 
-def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, out=None, wpack=None, heavy=None, table_own=None, n_rows=None):
+def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, out=None, wpack=None, heavy=None, table_own=None, n_rows=None,
+                     stats_out=None):
     """`table_own` (int32 [N]): table mode — h_in is the (degree, class) table, nbr_idx entries are tagged (GraphPlan.tagged_idx).
-    `n_rows`: only the first n_rows rows of h_in are stage rows, the rest are rows their neighbour lists point at (quotient stages)."""
+    `n_rows`: only the first n_rows rows of h_in are stage rows, the rest are rows their neighbour lists point at (quotient stages).
+    `stats_out` [N, 2] (bf16x3 kernels): receives {mean, rstd} of every row's pre-LayerNorm state, for struct_stage_bwd(stats=...)."""
     N, H = h_in.shape
     if n_rows is not None:
         N = int(n_rows)
@@ -115,7 +117,8 @@ def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
     if use_x3(H):
         wpack = stage_wpack(Wc, Whh) if wpack is None else wpack
         _hip.call('mgv_struct_stage_fwd_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
-                  xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(h_out), *_heavy_args(heavy, H, h_in.device), ptr(table_own))
+                  xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(h_out), *_heavy_args(heavy, H, h_in.device), ptr(table_own),
+                  ptr(stats_out))
         return h_out
     assert table_own is None, 'table mode needs the bf16x3 kernels'
     _hip.call('mgv_struct_stage_fwd', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
@@ -160,7 +163,7 @@ def _stage_ws(H, N, device):
 
 
 def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, gy_direct, gy_agg,
-                     grads, need_input_grad=True, wpack=None, heavy=None, table_own=None, n_rows=None):
+                     grads, need_input_grad=True, wpack=None, heavy=None, table_own=None, n_rows=None, stats=None):
     """`grads` = dict of fp32 accumulators (dWc, dbc, dWhh, dbhh, dxtab, dln_w, dln_b), added to."""
     N, H = h_in.shape
     if n_rows is not None:
@@ -177,7 +180,7 @@ def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
                   xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(gy_direct),
                   ptr(gy_agg), ptr(g_direct), ptr(g_agg), ptr(grads['dWc']), ptr(grads['dbc']), ptr(grads['dWhh']),
                   ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')),
-                  ptr(ws), ws.numel(), *_heavy_args(heavy, H, h_in.device), ptr(table_own))
+                  ptr(ws), ws.numel(), *_heavy_args(heavy, H, h_in.device), ptr(table_own), ptr(stats))
         return g_direct, g_agg
     assert table_own is None, 'table mode needs the H = 64 bf16x3 backward'
     if use_x3(H):
@@ -243,16 +246,18 @@ class StructEncoderFn(torch.autograd.Function):
         h = None if first is not None else torch.ones(N, H, dtype=F32, device=dev)
         # table mode for the half round after the table one: bf16x3 H = 64 kernels, node ids and table rows fit a tagged 32-bit entry
         table_mode = first is not None and use_x3(H) and H == 64 and N < (1 << 24) and first[1] <= 256 and TABLE_MODE
-        states = []
+        states, stats = [], []
+        keep_stats = lw is not None and use_x3(H) and H == 64      # LayerNorm statistics kept for the bwd2 kernel
         for _ in range(rounds):
             for rev in (False, True):
                 p, i = plan.csr(rev)
                 w = par[5:] if rev else par[:5]
                 states.append(h)
+                stats.append(torch.empty((first[1] if h is None else N), 2, dtype=F32, device=dev) if keep_stats else None)
                 if h is None:
                     cid, C, tp, ti, tx = first
                     table = struct_stage_fwd(torch.ones(C, H, dtype=F32, device=dev), tp, ti, tx, w[0], w[1], w[2], w[3], w[4],
-                                             lw, lb, wpack=packs[0])
+                                             lw, lb, wpack=packs[0], stats_out=stats[-1])
                     if table_mode:
                         h = ('table', table)     # never expanded to N rows: the next half round reads the table through tagged entries
                     else:
@@ -260,11 +265,12 @@ class StructEncoderFn(torch.autograd.Function):
                         _hip.call('mgv_class_expand', H, N, ptr(table), ptr(cid), ptr(h))
                 elif isinstance(h, tuple):
                     h = struct_stage_fwd(h[1], p, plan.tagged_idx(rev, first[0]), xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)],
-                                         heavy=plan.heavy(rev), table_own=first[0])
+                                         heavy=plan.heavy(rev), table_own=first[0], stats_out=stats[-1])
                 else:
-                    h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)], heavy=plan.heavy(rev))
+                    h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)], heavy=plan.heavy(rev),
+                                         stats_out=stats[-1])
         ctx.plan, ctx.xcls, ctx.rounds, ctx.packs, ctx.first = plan, xcls, rounds, packs, first
-        ctx.par, ctx.lw, ctx.lb, ctx.states = par, lw, lb, states
+        ctx.par, ctx.lw, ctx.lb, ctx.states, ctx.stats = par, lw, lb, states, stats
         ctx.quot = None
         return h
 
@@ -273,7 +279,8 @@ class StructEncoderFn(torch.autograd.Function):
         """Half rounds 1..len(quot) on one row per colour (inputs: the previous stage's table, stacked behind the representatives'
         own rows), the table of the last one expanded to N rows, the remaining half rounds as usual."""
         N, H, dev = plan.N, par[3].shape[1], par[3].device
-        states = []
+        states, stats = [], []
+        keep_stats = lw is not None and use_x3(H) and H == 64
         table = torch.ones(1, H, dtype=F32, device=dev)
         h = None
         for k in range(2 * rounds):
@@ -283,17 +290,20 @@ class StructEncoderFn(torch.autograd.Function):
                 st = quot[k]
                 h_cat = torch.cat([table.index_select(0, st['own']), table])
                 states.append(h_cat)
+                stats.append(torch.empty(st['C'], 2, dtype=F32, device=dev) if keep_stats else None)
                 table = struct_stage_fwd(h_cat, st['ptr'], st['idx'], st['xcls'], w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)],
-                                         heavy=st['heavy'], n_rows=st['C'])
+                                         heavy=st['heavy'], n_rows=st['C'], stats_out=stats[-1])
                 if k + 1 == len(quot) or k + 1 == 2 * rounds:
                     h = torch.empty(N, H, dtype=F32, device=dev)
                     _hip.call('mgv_class_expand', H, N, ptr(table), ptr(st['cid']), ptr(h))
             else:
                 p, i = plan.csr(rev)
                 states.append(h)
-                h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)], heavy=plan.heavy(rev))
+                stats.append(torch.empty(N, 2, dtype=F32, device=dev) if keep_stats else None)
+                h = struct_stage_fwd(h, p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)], heavy=plan.heavy(rev),
+                                     stats_out=stats[-1])
         ctx.plan, ctx.xcls, ctx.rounds, ctx.packs, ctx.first = plan, xcls, rounds, packs, None
-        ctx.par, ctx.lw, ctx.lb, ctx.states = par, lw, lb, states
+        ctx.par, ctx.lw, ctx.lb, ctx.states, ctx.stats = par, lw, lb, states, stats
         ctx.quot = quot
         return h
 
@@ -317,7 +327,7 @@ class StructEncoderFn(torch.autograd.Function):
             if k >= len(quot):
                 p, i = plan.csr(rev)
                 g_direct, g_agg = struct_stage_bwd(ctx.states[k], p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb, g_direct, g_agg, g,
-                                                   need_input_grad=(k > 0), wpack=ctx.packs[int(rev)], heavy=plan.heavy(rev))
+                                                   need_input_grad=(k > 0), wpack=ctx.packs[int(rev)], heavy=plan.heavy(rev), stats=ctx.stats[k])
                 continue
             st = quot[k]
             if gsum is None:
@@ -327,12 +337,12 @@ class StructEncoderFn(torch.autograd.Function):
                 order, levels = st['sum_levels']
                 gsum = _seg_sums(H, levels, order, g_direct, g_agg, p, i)
             gd_c, ga_c = struct_stage_bwd(ctx.states[k], st['ptr'], st['idx'], st['xcls'], w[0], w[1], w[2], w[3], w[4], lw, lb, gsum, None, g,
-                                          need_input_grad=(k > 0), wpack=ctx.packs[int(rev)], heavy=st['heavy'], n_rows=st['C'])
+                                          need_input_grad=(k > 0), wpack=ctx.packs[int(rev)], heavy=st['heavy'], n_rows=st['C'], stats=ctx.stats[k])
             if k > 0:
                 # colour sums for stage k-1: a colour there collects the own-row gradients of the representatives that own it and the
                 # aggregate gradients of those that list it (deterministic gathers over the colour-level lists)
                 gsum = _seg_sums(H, st['own_levels'], st['own_rows'], gd_c) + _seg_sums(H, st['ent_levels'], st['ent_rows'], ga_c)
-        ctx.states = None
+        ctx.states = ctx.stats = None
         f, r = acc['f'], acc['r']
         return (None, None, None, f['dxtab'], f['dWc'], f['dbc'], f['dWhh'], f['dbhh'],
                 r['dxtab'], r['dWc'], r['dbc'], r['dWhh'], r['dbhh'], dlw, dlb)
@@ -366,17 +376,17 @@ class StructEncoderFn(torch.autograd.Function):
                     ws = workspace(_hip.call_value('mgv_class_pull_sum_ws_floats', H, plan.N, C), g_direct.device)
                     _hip.call('mgv_class_pull_sum', H, plan.N, ptr(g_direct), ptr(g_agg), ptr(p), ptr(i), ptr(cid), C, ptr(gsum), ptr(ws), ws.numel())
                     struct_stage_bwd(torch.ones(C, H, dtype=F32, device=g_direct.device), tp, ti, tx, w[0], w[1], w[2], w[3], w[4],
-                                     lw, lb, gsum, None, g, need_input_grad=False, wpack=ctx.packs[0])
+                                     lw, lb, gsum, None, g, need_input_grad=False, wpack=ctx.packs[0], stats=ctx.stats[k])
                 elif isinstance(ctx.states[k], tuple):
                     g_direct, g_agg = struct_stage_bwd(ctx.states[k][1], p, plan.tagged_idx(rev, ctx.first[0]), xcls, w[0], w[1], w[2], w[3], w[4],
                                                        lw, lb, g_direct, g_agg, g, need_input_grad=(k > 0), wpack=ctx.packs[int(rev)],
-                                                       heavy=plan.heavy(rev), table_own=ctx.first[0])
+                                                       heavy=plan.heavy(rev), table_own=ctx.first[0], stats=ctx.stats[k])
                 else:
                     g_direct, g_agg = struct_stage_bwd(ctx.states[k], p, i, xcls, w[0], w[1], w[2], w[3], w[4], lw, lb,
                                                        g_direct, g_agg, g, need_input_grad=(k > 0), wpack=ctx.packs[int(rev)],
-                                                       heavy=plan.heavy(rev))
+                                                       heavy=plan.heavy(rev), stats=ctx.stats[k])
                 k -= 1
-        ctx.states = None
+        ctx.states = ctx.stats = None
         f, r = acc['f'], acc['r']
         return (None, None, None, f['dxtab'], f['dWc'], f['dbc'], f['dWhh'], f['dbhh'],
                 r['dxtab'], r['dWc'], r['dbc'], r['dWhh'], r['dbhh'], dlw, dlb)

@@ -48,6 +48,7 @@ def main():
     lw, lb = torch.rand(H, device=dev) + 0.5, torch.randn(H, device=dev) * 0.1
     wpack = ops.stage_wpack(Wc, Whh)
     out = torch.empty_like(h)
+    stats = torch.empty(N, 2, device=dev)      # LayerNorm statistics the forward keeps for the second backward kernel
     gy, ga_in = torch.randn(N, H, device=dev), torch.randn(N, H, device=dev)
     ws = ops._stage_ws(H, N, dev)
 
@@ -62,7 +63,7 @@ def main():
 
         def fwd():
             _hip.call('mgv_struct_stage_fwd_x3', H, N, ptr(h), ptr(p), ptr(i), ptr(xcls), ptr(xtab), C, ptr(wpack), ptr(bc), ptr(bhh),
-                      ptr(lw), ptr(lb), 1e-5, ptr(out), 0, None, None, None)
+                      ptr(lw), ptr(lb), 1e-5, ptr(out), 0, None, None, None, ptr(stats))
 
         res = {}
 
@@ -72,7 +73,8 @@ def main():
             if which == 1:
                 _hip.call('mgv_struct_stage_bwd_x3', *common, 0, None, None, None)
             else:
-                _hip.call('mgv_struct_stage_bwd%d_x3' % which, *common, ptr(ws), ws.numel(), 0, None, None, None)
+                _hip.call('mgv_struct_stage_bwd%d_x3' % which, *common, ptr(ws), ws.numel(), 0, None, None, None,
+                          ptr(stats) if os.environ.get('STAGE_NO_STATS') != '1' else None)
 
         t_f = timed(fwd, iters)
         line = '%s fwd %.3f ms' % (tag, t_f)
