@@ -106,9 +106,11 @@ def _negative_edges(rng, edge_index, n, count):
         s = rng.integers(0, n, size=m + 16)
         d = rng.integers(0, n, size=m + 16)
         kk = s * n + d
-        pos = np.searchsorted(key, kk)
-        pos[pos >= key.size] = key.size - 1
-        bad = (key[pos] == kk) | (s == d)
+        bad = s == d
+        if key.size:                      # (a graph of primary inputs only has no edge to collide with)
+            pos = np.searchsorted(key, kk)
+            pos[pos >= key.size] = key.size - 1
+            bad |= key[pos] == kk
         out = np.concatenate([out, np.stack([s[~bad], d[~bad]])], axis=1)
     return out[:, :count]
 

@@ -67,8 +67,9 @@ def multi_gcn_encoder(p, name, x, edge_index, rounds, layernorm=True):
     (aggr/update) and a reversed-edge half (aggr_r/update_r), the SAME LayerNorm after each."""
     N = x.shape[0]
     H = p[name + '.aggr.msg.weight'].shape[0]
-    h = torch.ones(N, H, dtype=torch.float32)
-    xf = x.to(torch.float32)
+    dt = p[name + '.aggr.msg.weight'].dtype          # fp32 like the reference; float64 parameters give a float64 restatement
+    h = torch.ones(N, H, dtype=dt)
+    xf = x.to(dt)
     src, dst = edge_index[0], edge_index[1]
 
     def ln(v):
@@ -148,7 +149,7 @@ def model_forward(p, ctype, batch, s_rounds=4, t_rounds=4, layernorm=True, num_r
     s, t = struct_encoder(p, ENC_PREFIX[ctype], one_hot, batch['edge_index'], s_rounds, t_rounds, layernorm)
     hs = linear(p, 'hs_linear', torch.cat([s, t], dim=-1))
     H = hs.shape[1]
-    hf = torch.zeros(N, H)
+    hf = torch.zeros(N, H, dtype=hs.dtype)
     if plan is None:
         plan = LevelPlan(ctype, batch['edge_index'], batch['gate'], batch['forward_level'])
     if fast:
