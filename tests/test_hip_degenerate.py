@@ -98,7 +98,7 @@ def check_step(ctype, graphs, weights=(1.0, 4.0, 4.0), H=64, rounds=2, seed=3, l
     R.weighted_loss(ols, list(weights)).backward()
     atol_g = 1e-4 if ops.PRECISION == 'f32' else 1e-3
     for k in ('recon_loss', 'prob_loss', 'func_loss'):
-        a, b = float(ls[k]), float(ols[k].detach())
+        a, b = float(ls[k].detach()), float(ols[k].detach())
         assert abs(a - b) <= loss_rtol * max(abs(b), 1e-3), (k, a, b)
     for k, q in model.named_parameters():
         ref = p[k].grad
