@@ -65,7 +65,9 @@ int mgv_struct_stage_bwd(int H, int64_t N, const float* h_in, const int32_t* nbr
  * with one workgroup per node instead of by one lane group inside the tile kernel (100,000 consumers: 38 ms per launch there).
  * table_own_idx (NULL = off): TABLE MODE for the half round that follows the (degree, class)-table one — h_in is the C-row table,
  * a node's own row is h_in[table_own_idx[node]], every nbr_idx entry carries its neighbour's table row in the top byte
- * (entry = node | row << 24, N < 2^24): the N x H expansion of the table is never gathered.
+ * (entry = node | row << 24, N < 2^24): the N x H expansion of the table is never gathered.  nbr_tagged = 0 with a table_own_idx:
+ * the entries are plain rows of h_in and only the own rows go through the index (the quotient stages, GraphPlan.quotient: h_in is the
+ * previous stage's colour table, a representative's own row is its previous colour's, its list names previous colours).
  * ln_stats_out (forward) / ln_stats (bwd2) [N][2], NULL = off: {mean, rstd} of every row's pre-LayerNorm state, kept by the forward
  * so that the backward's recompute needs two cross-lane row sums instead of four and no four-way combination of the column waves'
  * partial statistics (-3 % per backward launch); ignored when ln_w is NULL. */
@@ -73,14 +75,14 @@ int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, const int32_t* 
                             const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
                             const float* bhh, const float* ln_w, const float* ln_b, float ln_eps, float* h_out,
                             int heavy_n, const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx,
-                            float* ln_stats_out, void* stream);
+                            int nbr_tagged, float* ln_stats_out, void* stream);
 int mgv_struct_stage_bwd_x3(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
                             const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
                             const float* bhh, const float* ln_w, const float* ln_b, float ln_eps,
                             const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
                             float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
                             float* dln_b, int heavy_n, const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx,
-                            void* stream);
+                            int nbr_tagged, void* stream);
 
 /* Second decomposition of the bf16x3 backward (H = 64 only): all weight fragments register-resident, transposed
  * products, one dgrad+wgrad phase per tile, and NO float atomics: parameter gradients leave through per-workgroup
@@ -95,7 +97,7 @@ int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, const int32_t*
                              float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
                              float* dln_b, float* workspace, int64_t workspace_floats, int heavy_n,
                              const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx,
-                             const float* ln_stats, void* stream);
+                             int nbr_tagged, const float* ln_stats, void* stream);
 
 /* ---- Linear over node rows (hs_linear dg_ae_model_aig.py:64, hs_decompose :109, fc_{s,t}_{mu,logstd}
  * digvae_model.py:135-136, readout Linear layers mlp.py:29,38; also the dgrad with W^T):
@@ -143,9 +145,11 @@ int mgv_class_expand(int H, int64_t N, const float* table, const int32_t* class_
  * v(item(m)), item(m) = items ? items[m] : m, v(i) = direct[i] + (agg ? sum of agg[nbr_idx[e]] over i's nbr list : 0).  The per-class
  * sums of an incoming gradient for the quotient stages of the structural encoder (rows that are identical by construction are
  * computed once: digae_layer.py:260 starts every node from ones, so early half rounds have few distinct rows): level 1 sums runs of
- * <= 64 class members with the stage backward's neighbour pull fused, the next levels sum the partial rows. */
+ * <= 64 class members with the stage backward's neighbour pull fused, the next levels sum the partial rows.  out_row (NULL: segment s
+ * writes row s): the row of `out` each segment writes — a class that fits one segment writes its final row at once, only the classes
+ * with more members than that leave partial rows behind the C final ones for the next level (most colours have a few members). */
 int mgv_seg_sum(int H, int64_t n_seg, const int32_t* seg_ptr, const int32_t* items, const float* direct, const float* agg,
-                const int32_t* nbr_ptr, const int32_t* nbr_idx, float* out, void* stream);
+                const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* out_row, float* out, void* stream);
 
 int mgv_class_pull_sum_ws_floats(int H, int64_t N, int C);
 int mgv_class_pull_sum(int H, int64_t N, const float* gy_direct, const float* gy_agg, const int32_t* nbr_ptr,

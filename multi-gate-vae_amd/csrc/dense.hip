@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void k_class_pull_sum(int64_t N, const fl
 // to chance.  U members' loads are in flight together; the additions keep list order.
 template <int H>
 __global__ __launch_bounds__(kThreads) void k_seg_sum(int64_t n_seg, const int32_t* seg_ptr, const int32_t* items, const float* direct,
-                                                     const float* agg, const int32_t* ptr, const int32_t* idx, float* out) {
+                                                     const float* agg, const int32_t* ptr, const int32_t* idx, const int32_t* out_row, float* out) {
     constexpr int LPR = H / 4, U = 4, D = 2;
     const int lr = threadIdx.x % LPR;
     const int64_t stride = (int64_t)gridDim.x * (kThreads / LPR);
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(kThreads) void k_seg_sum(int64_t n_seg, const int32
                 acc = add4(acc, v);
             }
         }
-        st4(out + s * H + 4 * lr, acc);
+        st4(out + (out_row ? (int64_t)out_row[s] : s) * H + 4 * lr, acc);
     }
 }
 
@@ -378,17 +378,17 @@ extern "C" int mgv_gather_sum(int H, int64_t N, const float* h, const int32_t* n
 }
 
 extern "C" int mgv_seg_sum(int H, int64_t n_seg, const int32_t* seg_ptr, const int32_t* items, const float* direct, const float* agg,
-                           const int32_t* nbr_ptr, const int32_t* nbr_idx, float* out, void* stream) {
+                           const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* out_row, float* out, void* stream) {
     MGV_CHECK_ARG(n_seg >= 0 && seg_ptr && direct && out && (!agg || (nbr_ptr && nbr_idx)));
     if (n_seg == 0) return MGV_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t rows_per_block = mgv::kThreads / (H / 4);
     const int grid = mgv::grid_for((n_seg + rows_per_block - 1) / rows_per_block, 16);
     switch (H) {
-        case 16: hipLaunchKernelGGL(mgv::k_seg_sum<16>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out); break;
-        case 32: hipLaunchKernelGGL(mgv::k_seg_sum<32>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out); break;
-        case 64: hipLaunchKernelGGL(mgv::k_seg_sum<64>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out); break;
-        case 128: hipLaunchKernelGGL(mgv::k_seg_sum<128>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out); break;
+        case 16: hipLaunchKernelGGL(mgv::k_seg_sum<16>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out_row, out); break;
+        case 32: hipLaunchKernelGGL(mgv::k_seg_sum<32>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out_row, out); break;
+        case 64: hipLaunchKernelGGL(mgv::k_seg_sum<64>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out_row, out); break;
+        case 128: hipLaunchKernelGGL(mgv::k_seg_sum<128>, dim3(grid), dim3(mgv::kThreads), 0, st, n_seg, seg_ptr, items, direct, agg, nbr_ptr, nbr_idx, out_row, out); break;
         default: return MGV_EUNSUPPORTED;
     }
     MGV_LAUNCH_RET();

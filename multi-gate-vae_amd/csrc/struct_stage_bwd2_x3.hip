@@ -663,7 +663,7 @@ extern "C" int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, con
                                         float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
                                         float* dln_b, float* workspace, int64_t workspace_floats, int heavy_n,
                                         const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx,
-                                        const float* ln_stats, void* stream) {
+                                        int nbr_tagged, const float* ln_stats, void* stream) {
     MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && gy_direct);
     MGV_CHECK_ARG(dWc && dbc && dWhh && dbhh && dxtab);
     MGV_CHECK_ARG(C >= 1 && C <= mgv::kMaxClsX3);
@@ -679,12 +679,12 @@ extern "C" int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, con
     a.gy_direct = gy_direct; a.gy_agg = gy_agg; a.g_direct_out = g_direct_out; a.g_agg_out = g_agg_out;
     a.dWc = dWc; a.dbc = dbc; a.dWhh = dWhh; a.dbhh = dbhh; a.dxtab = dxtab; a.dlnw = dln_w; a.dlnb = dln_b;
     a.gmask = -1;
-    MGV_CHECK_ARG(table_own_idx == nullptr || N < (1 << 24));
-    if (table_own_idx) { a.hshift = 24; a.gmask = 0xffffff; a.own_idx = table_own_idx; }
+    MGV_CHECK_ARG(table_own_idx == nullptr || !nbr_tagged || N < (1 << 24));
+    if (table_own_idx) { a.own_idx = table_own_idx; if (nbr_tagged) { a.hshift = 24; a.gmask = 0xffffff; } }
     a.ln_stats = ln_w ? const_cast<float*>(ln_stats) : nullptr;
     MGV_SET_STAMPS2(a);
     a.xcd = 1;           // XCD-contiguous tile order and the L2 row prefetch: both measured, no switch left
-    a.prefetch = 1;
+    a.prefetch = (table_own_idx && !nbr_tagged) ? 0 : 1;      // (own rows through an index into a shorter h_in: the row prefetch assumes N rows behind h_in)
     MGV_CHECK_ARG(heavy_n >= 0 && (heavy_n == 0 || (heavy_nodes && heavy_ws)));
     mgv::launch_heavy_sums<64>(a, heavy_n, heavy_nodes, heavy_ws, gy_agg != nullptr, static_cast<hipStream_t>(stream));
     return mgv::launch_bwd2_x3(a, workspace, workspace_floats, static_cast<hipStream_t>(stream));

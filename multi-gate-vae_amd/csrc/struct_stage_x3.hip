@@ -680,8 +680,8 @@ extern "C" int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, cons
                                        const uint8_t* xcls, const float* xtab, int C, const void* wpack_bf16, const float* bc,
                                        const float* bhh, const float* ln_w, const float* ln_b, float ln_eps, float* h_out,
                                        int heavy_n, const int32_t* heavy_nodes, float* heavy_ws, const int32_t* table_own_idx,
-                                       float* ln_stats_out, void* stream) {
-    MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && h_out && (table_own_idx == nullptr || N < (1 << 24)));
+                                       int nbr_tagged, float* ln_stats_out, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && h_out && (table_own_idx == nullptr || !nbr_tagged || N < (1 << 24)));
     MGV_CHECK_ARG(heavy_n >= 0 && (heavy_n == 0 || (heavy_nodes && heavy_ws)));
     MGV_CHECK_ARG(C >= 1 && C <= mgv::kMaxClsX3);
     MGV_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr));
@@ -691,7 +691,7 @@ extern "C" int mgv_struct_stage_fwd_x3(int H, int64_t N, const float* h_in, cons
     a.N = N; a.h_in = h_in; a.ptr = nbr_ptr; a.idx = nbr_idx; a.xcls = xcls; a.xtab = xtab; a.C = C;
     a.wpack = static_cast<const __bf16*>(wpack_bf16); a.bc = bc; a.bhh = bhh; a.lnw = ln_w; a.lnb = ln_b; a.eps = ln_eps; a.h_out = h_out;
     a.gmask = -1;
-    if (table_own_idx) { a.hshift = 24; a.gmask = 0xffffff; a.own_idx = table_own_idx; }
+    if (table_own_idx) { a.own_idx = table_own_idx; if (nbr_tagged) { a.hshift = 24; a.gmask = 0xffffff; } }
     a.ln_stats = ln_w ? ln_stats_out : nullptr;
     MGV_SET_STAMPS(a);
     a.xcd = xcd_tiles();
@@ -709,8 +709,8 @@ extern "C" int mgv_struct_stage_bwd_x3(int H, int64_t N, const float* h_in, cons
                                        const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
                                        float* dWc, float* dbc, float* dWhh, float* dbhh, float* dxtab, float* dln_w,
                                        float* dln_b, int heavy_n, const int32_t* heavy_nodes, float* heavy_ws,
-                                       const int32_t* table_own_idx, void* stream) {
-    MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && gy_direct && (table_own_idx == nullptr || N < (1 << 24)));
+                                       const int32_t* table_own_idx, int nbr_tagged, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xcls && xtab && wpack_bf16 && bc && bhh && gy_direct && (table_own_idx == nullptr || !nbr_tagged || N < (1 << 24)));
     MGV_CHECK_ARG(heavy_n >= 0 && (heavy_n == 0 || (heavy_nodes && heavy_ws)));
     MGV_CHECK_ARG(dWc && dbc && dWhh && dbhh && dxtab);
     MGV_CHECK_ARG(C >= 1 && C <= mgv::kMaxClsX3);
@@ -725,7 +725,7 @@ extern "C" int mgv_struct_stage_bwd_x3(int H, int64_t N, const float* h_in, cons
     a.gy_direct = gy_direct; a.gy_agg = gy_agg; a.g_direct_out = g_direct_out; a.g_agg_out = g_agg_out;
     a.dWc = dWc; a.dbc = dbc; a.dWhh = dWhh; a.dbhh = dbhh; a.dxtab = dxtab; a.dlnw = dln_w; a.dlnb = dln_b;
     a.gmask = -1;
-    if (table_own_idx) { a.hshift = 24; a.gmask = 0xffffff; a.own_idx = table_own_idx; }
+    if (table_own_idx) { a.own_idx = table_own_idx; if (nbr_tagged) { a.hshift = 24; a.gmask = 0xffffff; } }
     MGV_SET_STAMPS(a);
     a.xcd = xcd_tiles();
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -250,7 +250,9 @@ class GraphPlan:
         t = 1, 2, ... (possibly empty), each a dict:
             C        colours after the stage;  cid [N] int32 colour of every node;  rev  the stage gathers over the out-CSR
             ptr [C+1], idx int32: a representative's neighbour list, entries = C + (colour after t-1) — rows of the stacked input
-                     [own rows (C) | table of stage t-1 (C_prev)] the stage kernel reads;  own [C] int64: colour after t-1
+                     [own rows (C) | table of stage t-1 (C_prev)] the fp32 stage kernels read;  own [C] int64: colour after t-1;
+                     ent_idx / own32: the same lists and own colours as plain int32 rows of the table of stage t-1 (the bf16x3
+                     kernels read that table in place: own rows through own32)
             xcls [C] uint8, heavy: (count, rows with more than HEAVY_ROW neighbours)
             own_rows/own_levels, ent_rows/ent_levels: per colour of stage t-1 the representatives that own it / whose lists name it,
                      as segment tables of mgv_seg_sum (backward)
@@ -344,7 +346,9 @@ class GraphPlan:
                 ent_o, ent_levels = self.class_sum_levels(ent, Cp)
                 stages.append(dict(C=C, cid=inv.to(torch.int32).contiguous(), rev=rev, ptr=rptr.to(torch.int32).contiguous(),
                                    idx=(ent + C).to(torch.int32).contiguous() if n_ent else torch.zeros(1, dtype=torch.int32, device=dev),
-                                   own=own, xcls=xcls[rep].contiguous(), heavy=(int(heavy.numel()), heavy.contiguous()),
+                                   ent_idx=ent.to(torch.int32).contiguous() if n_ent else torch.zeros(1, dtype=torch.int32, device=dev),
+                                   own=own, own32=own.to(torch.int32).contiguous(), xcls=xcls[rep].contiguous(),
+                                   heavy=(int(heavy.numel()), heavy.contiguous()),
                                    own_rows=own_o, own_levels=own_levels,
                                    ent_rows=row[ent_o.long()].to(torch.int32).contiguous() if n_ent else torch.zeros(1, dtype=torch.int32, device=dev),
                                    ent_levels=ent_levels))
@@ -358,9 +362,12 @@ class GraphPlan:
         return stages
 
     def class_sum_levels(self, cid, C, seg=64, presorted=None):
-        """Segment tables of mgv_seg_sum for per-colour row sums: (order [N] int32 = nodes sorted by colour, [(n_seg, seg_ptr)] per
-        level).  Level 1 cuts every colour's run of members into segments of <= seg, level l+1 does the same with level l's
-        partial rows, until every colour is one segment; the last level's rows are the colours in order."""
+        """Segment tables of mgv_seg_sum for per-colour row sums: (order [N] int32 = nodes sorted by colour, tables) with
+        tables = dict(C, rows, levels=[(n_seg, seg_ptr int32, out_row int32 | None, src_row)]).  The sums live in ONE buffer of
+        `rows` rows: the first C are the colours' sums, partial rows follow.  Level 1 cuts every colour's run of members into
+        segments of <= seg: a colour that fits one segment writes its final row, the others leave one partial row per segment
+        (colour by colour, in order) from row C on; level l+1 does the same with the partial rows level l left at `src_row`
+        — only for the colours that still have more than one — until none is left."""
         dev = self.device
         i64 = dict(dtype=torch.int64, device=dev)
         if presorted is not None:            # (items already sorted by colour, members per colour)
@@ -369,19 +376,30 @@ class GraphPlan:
             order = torch.sort(cid.long(), stable=True).indices.to(torch.int32).contiguous()
             counts = torch.bincount(cid.long(), minlength=C)
         levels = []
+        gid = torch.arange(C, **i64)         # the colours still being summed
+        base, src_row = C, 0
         while True:
+            G = int(gid.numel())
             nseg = torch.clamp((counts + seg - 1) // seg, min=1)         # (a colour nobody carries still gets its zero row)
-            total = int(nseg.sum().item())
-            cls = torch.repeat_interleave(torch.arange(C, **i64), nseg)
+            cls = torch.repeat_interleave(torch.arange(G, **i64), nseg)
+            total = int(cls.numel())
             first = torch.cumsum(nseg, 0) - nseg
             start = torch.cumsum(counts, 0) - counts
             sp = torch.empty(total + 1, **i64)
             sp[:total] = start[cls] + seg * (torch.arange(total, **i64) - first[cls])
             sp[total] = counts.sum()
-            levels.append((total, sp.to(torch.int32).contiguous()))
-            if total == C:
-                return order, levels
-            counts = nseg
+            multi = nseg > 1
+            seg_multi = multi[cls]
+            n_partial = int(seg_multi.sum().item())
+            if n_partial == 0 and G == C and base == C:
+                out_row = None                                           # every colour is one segment: segment s writes row s
+            else:
+                out_row = torch.where(seg_multi, base + torch.cumsum(seg_multi, 0) - 1, gid[cls]).to(torch.int32).contiguous()
+            levels.append((total, sp.to(torch.int32).contiguous(), out_row, src_row))
+            if n_partial == 0:
+                return order, dict(C=C, rows=base, levels=levels)
+            gid, counts = gid[multi], nseg[multi]
+            src_row, base = base, base + n_partial
 
     def _first_stage_classes_hip(self, xcls, max_classes):
         from . import _hip

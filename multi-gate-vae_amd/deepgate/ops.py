@@ -98,8 +98,10 @@ def _heavy_args(heavy, H, device):
 
 
 def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, out=None, wpack=None, heavy=None, table_own=None, n_rows=None,
-                     stats_out=None):
-    """`table_own` (int32 [N]): table mode — h_in is the (degree, class) table, nbr_idx entries are tagged (GraphPlan.tagged_idx).
+                     stats_out=None, tagged=True):
+    """`table_own` (int32 [N]): table mode — h_in is the (degree, class) table, nbr_idx entries are tagged (GraphPlan.tagged_idx);
+    with `tagged=False` the entries are plain rows of h_in and only the own rows go through table_own (quotient stages: h_in is the
+    previous stage's colour table).
     `n_rows`: only the first n_rows rows of h_in are stage rows, the rest are rows their neighbour lists point at (quotient stages).
     `stats_out` [N, 2] (bf16x3 kernels): receives {mean, rstd} of every row's pre-LayerNorm state, for struct_stage_bwd(stats=...)."""
     N, H = h_in.shape
@@ -118,7 +120,7 @@ def struct_stage_fwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
         wpack = stage_wpack(Wc, Whh) if wpack is None else wpack
         _hip.call('mgv_struct_stage_fwd_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
                   xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(h_out), *_heavy_args(heavy, H, h_in.device), ptr(table_own),
-                  ptr(stats_out))
+                  int(bool(tagged)), ptr(stats_out))
         return h_out
     assert table_own is None, 'table mode needs the bf16x3 kernels'
     _hip.call('mgv_struct_stage_fwd', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
@@ -163,7 +165,7 @@ def _stage_ws(H, N, device):
 
 
 def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w, ln_b, gy_direct, gy_agg,
-                     grads, need_input_grad=True, wpack=None, heavy=None, table_own=None, n_rows=None, stats=None):
+                     grads, need_input_grad=True, wpack=None, heavy=None, table_own=None, n_rows=None, stats=None, tagged=True):
     """`grads` = dict of fp32 accumulators (dWc, dbc, dWhh, dbhh, dxtab, dln_w, dln_b), added to."""
     N, H = h_in.shape
     if n_rows is not None:
@@ -180,9 +182,9 @@ def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
                   xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(gy_direct),
                   ptr(gy_agg), ptr(g_direct), ptr(g_agg), ptr(grads['dWc']), ptr(grads['dbc']), ptr(grads['dWhh']),
                   ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')),
-                  ptr(ws), ws.numel(), *_heavy_args(heavy, H, h_in.device), ptr(table_own), ptr(stats))
+                  ptr(ws), ws.numel(), *_heavy_args(heavy, H, h_in.device), ptr(table_own), int(bool(tagged)), ptr(stats))
         return g_direct, g_agg
-    assert table_own is None, 'table mode needs the H = 64 bf16x3 backward'
+    assert table_own is None or not tagged, 'table mode needs the H = 64 bf16x3 backward'
     if use_x3(H):
         g_direct = torch.empty(N, H, dtype=F32, device=h_in.device) if need_input_grad else None
         g_agg = torch.empty(N, H, dtype=F32, device=h_in.device) if need_input_grad else None
@@ -190,8 +192,9 @@ def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
         _hip.call('mgv_struct_stage_bwd_x3', H, N, ptr(h_in), ptr(nbr_ptr), ptr(nbr_idx), ptr(xcls), ptr(xtab),
                   xtab.shape[0], ptr(wpack), ptr(bc), ptr(bhh), ptr(ln_w), ptr(ln_b), LN_EPS, ptr(gy_direct),
                   ptr(gy_agg), ptr(g_direct), ptr(g_agg), ptr(grads['dWc']), ptr(grads['dbc']), ptr(grads['dWhh']),
-                  ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')), *_heavy_args(heavy, H, h_in.device), None)
+                  ptr(grads['dbhh']), ptr(grads['dxtab']), ptr(grads.get('dln_w')), ptr(grads.get('dln_b')), *_heavy_args(heavy, H, h_in.device), ptr(table_own), 0)
         return g_direct, g_agg
+    assert table_own is None, 'own rows through an index need the bf16x3 kernels'
     WcT = Wc.t().contiguous()
     WhhT = Whh.t().contiguous()
     g_direct = torch.empty(N, H, dtype=F32, device=h_in.device) if need_input_grad else None
@@ -204,18 +207,16 @@ def struct_stage_bwd(h_in, nbr_ptr, nbr_idx, xcls, xtab, Wc, bc, Whh, bhh, ln_w,
     return g_direct, g_agg
 
 
-def _seg_sums(H, levels, items, direct, agg=None, nbr_ptr=None, nbr_idx=None):
+def _seg_sums(H, tables, items, direct, agg=None, nbr_ptr=None, nbr_idx=None):
     """Per-group row sums through the segment tables of GraphPlan.class_sum_levels: level 1 reads rows `items` of `direct` (+ the
-    neighbour pull of `agg`), every further level the partial rows of the one before; the last level's rows are the groups."""
-    rows = None
-    for li, (n_seg, seg_ptr) in enumerate(levels):
-        out = torch.empty(n_seg, H, dtype=F32, device=direct.device)
+    neighbour pull of `agg`), every further level the partial rows the one before left behind the C final rows of the same buffer."""
+    buf = torch.empty(tables['rows'], H, dtype=F32, device=direct.device)
+    for li, (n_seg, seg_ptr, out_row, src_row) in enumerate(tables['levels']):
         if li == 0:
-            _hip.call('mgv_seg_sum', H, n_seg, ptr(seg_ptr), ptr(items), ptr(direct), ptr(agg), ptr(nbr_ptr), ptr(nbr_idx), ptr(out))
+            _hip.call('mgv_seg_sum', H, n_seg, ptr(seg_ptr), ptr(items), ptr(direct), ptr(agg), ptr(nbr_ptr), ptr(nbr_idx), ptr(out_row), ptr(buf))
         else:
-            _hip.call('mgv_seg_sum', H, n_seg, ptr(seg_ptr), None, ptr(rows), None, None, None, ptr(out))
-        rows = out
-    return rows
+            _hip.call('mgv_seg_sum', H, n_seg, ptr(seg_ptr), None, ptr(buf[src_row:]), None, None, None, ptr(out_row), ptr(buf))
+    return buf[:tables['C']]
 
 
 class StructEncoderFn(torch.autograd.Function):
@@ -288,11 +289,17 @@ class StructEncoderFn(torch.autograd.Function):
             w = par[5:] if rev else par[:5]
             if k < len(quot):
                 st = quot[k]
-                h_cat = torch.cat([table.index_select(0, st['own']), table])
-                states.append(h_cat)
                 stats.append(torch.empty(st['C'], 2, dtype=F32, device=dev) if keep_stats else None)
-                table = struct_stage_fwd(h_cat, st['ptr'], st['idx'], st['xcls'], w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)],
-                                         heavy=st['heavy'], n_rows=st['C'], stats_out=stats[-1])
+                if use_x3(H):
+                    # the bf16x3 kernels read the previous table in place: own rows through st['own32'], lists name its rows
+                    states.append(table)
+                    table = struct_stage_fwd(table, st['ptr'], st['ent_idx'], st['xcls'], w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)],
+                                             heavy=st['heavy'], table_own=st['own32'], tagged=False, stats_out=stats[-1])
+                else:
+                    h_cat = torch.cat([table.index_select(0, st['own']), table])
+                    states.append(h_cat)
+                    table = struct_stage_fwd(h_cat, st['ptr'], st['idx'], st['xcls'], w[0], w[1], w[2], w[3], w[4], lw, lb, wpack=packs[int(rev)],
+                                             heavy=st['heavy'], n_rows=st['C'], stats_out=stats[-1])
                 if k + 1 == len(quot) or k + 1 == 2 * rounds:
                     h = torch.empty(N, H, dtype=F32, device=dev)
                     _hip.call('mgv_class_expand', H, N, ptr(table), ptr(st['cid']), ptr(h))
@@ -336,8 +343,13 @@ class StructEncoderFn(torch.autograd.Function):
                 p, i = plan.csr(rev)
                 order, levels = st['sum_levels']
                 gsum = _seg_sums(H, levels, order, g_direct, g_agg, p, i)
-            gd_c, ga_c = struct_stage_bwd(ctx.states[k], st['ptr'], st['idx'], st['xcls'], w[0], w[1], w[2], w[3], w[4], lw, lb, gsum, None, g,
-                                          need_input_grad=(k > 0), wpack=ctx.packs[int(rev)], heavy=st['heavy'], n_rows=st['C'], stats=ctx.stats[k])
+            if use_x3(H):
+                gd_c, ga_c = struct_stage_bwd(ctx.states[k], st['ptr'], st['ent_idx'], st['xcls'], w[0], w[1], w[2], w[3], w[4], lw, lb, gsum, None, g,
+                                              need_input_grad=(k > 0), wpack=ctx.packs[int(rev)], heavy=st['heavy'], table_own=st['own32'], tagged=False,
+                                              stats=ctx.stats[k])
+            else:
+                gd_c, ga_c = struct_stage_bwd(ctx.states[k], st['ptr'], st['idx'], st['xcls'], w[0], w[1], w[2], w[3], w[4], lw, lb, gsum, None, g,
+                                              need_input_grad=(k > 0), wpack=ctx.packs[int(rev)], heavy=st['heavy'], n_rows=st['C'], stats=ctx.stats[k])
             if k > 0:
                 # colour sums for stage k-1: a colour there collects the own-row gradients of the representatives that own it and the
                 # aggregate gradients of those that list it (deterministic gathers over the colour-level lists)

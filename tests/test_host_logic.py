@@ -319,9 +319,19 @@ def test_quotient_colours_equal_brute_force_refinement(ctype):
     order, levels = q[-1]['sum_levels']
     cid = q[-1]['cid']
     assert sorted(order.tolist()) == list(range(N)) and bool((cid[order.long()][1:] >= cid[order.long()][:-1]).all())
-    n_items = N
-    for n_seg, sp in levels:
+    # run the tables the way mgv_seg_sum does (out[out_row[s]] = sum of the segment's items) on one number per node: every colour's
+    # final row must be its member count, every segment <= 64 items, every row of the buffer written exactly once
+    C = q[-1]['C']
+    assert levels['C'] == C and levels['rows'] >= C
+    buf = [None] * levels['rows']
+    for li, (n_seg, sp, out_row, src_row) in enumerate(levels['levels']):
         sp = sp.tolist()
-        assert len(sp) == n_seg + 1 and sp[0] == 0 and sp[-1] == n_items and all(0 <= b - a_ <= 64 for a_, b in zip(sp[:-1], sp[1:]))
-        n_items = n_seg
-    assert n_items == q[-1]['C']
+        rows = out_row.tolist() if out_row is not None else list(range(n_seg))
+        assert len(sp) == n_seg + 1 and sp[0] == 0 and all(0 <= b - a_ <= 64 for a_, b in zip(sp[:-1], sp[1:]))
+        src = [1] * N if li == 0 else buf[src_row:]
+        assert sp[-1] == (N if li == 0 else len([v for v in src if v is not None]))
+        for s_, r in enumerate(rows):
+            assert buf[r] is None
+            buf[r] = sum(src[m] for m in range(sp[s_], sp[s_ + 1]))
+    assert all(v is not None for v in buf)
+    assert buf[:C] == torch.bincount(cid.long(), minlength=C).tolist()

@@ -60,9 +60,9 @@ def main():
         gd, gg = torch.empty_like(h), torch.empty_like(h)
         stats = torch.empty(N, 2, device=dev)
         tf = timed(lambda: _hip.call('mgv_struct_stage_fwd_x3', H, N, ptr(h), ptr(p), ptr(i), ptr(xcls), ptr(xtab), C, ptr(wpack), ptr(bc), ptr(bhh),
-                                     ptr(lw), ptr(lb), 1e-5, ptr(out), *hv, None, ptr(stats)))
+                                     ptr(lw), ptr(lb), 1e-5, ptr(out), *hv, None, 0, ptr(stats)))
         tb = timed(lambda: _hip.call('mgv_struct_stage_bwd2_x3', H, N, ptr(h), ptr(p), ptr(i), ptr(xcls), ptr(xtab), C, ptr(wpack), ptr(bc), ptr(bhh),
-                                     ptr(lw), ptr(lb), 1e-5, ptr(gy), ptr(ga), ptr(gd), ptr(gg), *[ptr(t) for t in acc], ptr(ws), ws.numel(), *hv, None, ptr(stats)))
+                                     ptr(lw), ptr(lb), 1e-5, ptr(gy), ptr(ga), ptr(gd), ptr(gg), *[ptr(t) for t in acc], ptr(ws), ws.numel(), *hv, None, 0, ptr(stats)))
         print('%-24s N=%d E=%d: out-CSR forward %.3f ms, backward %.3f ms' % (label, N, ei.shape[1], tf, tb))
 
 

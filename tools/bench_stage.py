@@ -63,7 +63,7 @@ def main():
 
         def fwd():
             _hip.call('mgv_struct_stage_fwd_x3', H, N, ptr(h), ptr(p), ptr(i), ptr(xcls), ptr(xtab), C, ptr(wpack), ptr(bc), ptr(bhh),
-                      ptr(lw), ptr(lb), 1e-5, ptr(out), 0, None, None, None, ptr(stats))
+                      ptr(lw), ptr(lb), 1e-5, ptr(out), 0, None, None, None, 0, ptr(stats))
 
         res = {}
 
@@ -71,9 +71,9 @@ def main():
             common = (H, N, ptr(h), ptr(p), ptr(i), ptr(xcls), ptr(xtab), C, ptr(wpack), ptr(bc), ptr(bhh), ptr(lw), ptr(lb), 1e-5,
                       ptr(gy), ptr(ga_in), ptr(gd), ptr(ga), *[ptr(t) for t in acc])
             if which == 1:
-                _hip.call('mgv_struct_stage_bwd_x3', *common, 0, None, None, None)
+                _hip.call('mgv_struct_stage_bwd_x3', *common, 0, None, None, None, 0)
             else:
-                _hip.call('mgv_struct_stage_bwd%d_x3' % which, *common, ptr(ws), ws.numel(), 0, None, None, None,
+                _hip.call('mgv_struct_stage_bwd%d_x3' % which, *common, ptr(ws), ws.numel(), 0, None, None, None, 0,
                           ptr(stats) if os.environ.get('STAGE_NO_STATS') != '1' else None)
 
         t_f = timed(fwd, iters)

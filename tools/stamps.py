@@ -45,7 +45,7 @@ def main():
         ptr, idx = plan.csr(rev)
         stamps.zero_()
         rc = lib.mgv_diag_struct_stage_fwd_x3_impl(H, ctypes.c_int64(N), P(h), P(ptr), P(idx), P(xcls), P(xtab), 6, P(wpack), P(bc), P(bhh),
-                                                   P(lw), P(lb), ctypes.c_float(1e-5), P(out), 0, None, None, None, None, st)
+                                                   P(lw), P(lb), ctypes.c_float(1e-5), P(out), 0, None, None, None, 0, None, st)
         torch.cuda.synchronize()
         assert rc == 0
         t = stamps.view(8, 16).double().cpu()
@@ -60,7 +60,7 @@ def main():
                torch.zeros(3 * H, device=dev), torch.zeros(6, 3 * H, device=dev), torch.zeros(H, device=dev), torch.zeros(H, device=dev)]
         stamps.zero_()
         rc = lib.mgv_diag_struct_stage_bwd_x3_impl(H, ctypes.c_int64(N), P(h), P(ptr), P(idx), P(xcls), P(xtab), 6, P(wpack), P(bc), P(bhh),
-                                                   P(lw), P(lb), ctypes.c_float(1e-5), P(gy), P(out), P(gd), P(ga), *[P(t_) for t_ in acc], 0, None, None, None, st)
+                                                   P(lw), P(lb), ctypes.c_float(1e-5), P(gy), P(out), P(gd), P(ga), *[P(t_) for t_ in acc], 0, None, None, None, 0, st)
         torch.cuda.synchronize()
         assert rc == 0
         t = stamps.view(8, 16).double().cpu()

@@ -47,7 +47,7 @@ def main():
         stamps.zero_()
         rc = lib.mgv_diag_struct_stage_bwd2_x3_impl(H, ctypes.c_int64(N), P(h), P(ptr), P(idx), P(xcls), P(xtab), C, P(wpack), P(bc), P(bhh),
                                                     P(lw), P(lb), ctypes.c_float(1e-5), P(gy), P(ga_in), P(gd), P(ga), *[P(t_) for t_ in acc],
-                                                    P(ws), ctypes.c_int64(n_ws), 0, None, None, None, None, st)
+                                                    P(ws), ctypes.c_int64(n_ws), 0, None, None, None, 0, None, st)
         torch.cuda.synchronize()
         assert rc == 0, rc
         t = stamps.view(8, 16).double().cpu()
