@@ -238,7 +238,8 @@ class GraphPlan:
         self._stage1 = (key, out)
         return out
 
-    QUOTIENT_FRACTION = 3.0    # a half round runs on distinct rows only while they are at most N / 3 (measured: DESIGN.md 4.3)
+    QUOTIENT_FRACTION = 2.0    # a half round runs on distinct rows only while they are at most N / 2 (measured: DESIGN.md 4.3)
+    QUOTIENT_GROWTH = 8        # colours multiply by at least this per half round (config 2: x50, x226, x48): the next one is not even tried if C * 8 would not qualify
 
     QUOTIENT_MIN_NODES = 16384   # below: a step is launch-bound, the extra small launches cost more than the rows save
 
@@ -354,8 +355,8 @@ class GraphPlan:
                                    ent_levels=ent_levels))
                 prev, Cp = inv, C
                 last_sorted = (by_colour, members)
-                if C * 64 * self.QUOTIENT_FRACTION > N:
-                    break                    # colours multiply by the fan-in / fan-out per half round: the next one would not qualify
+                if C * self.QUOTIENT_GROWTH * self.QUOTIENT_FRACTION > N:
+                    break                    # colours multiply per half round: the next one would not qualify
             if stages:
                 stages[-1]['sum_levels'] = self.class_sum_levels(stages[-1]['cid'], stages[-1]['C'], presorted=last_sorted)
         self._quotient = (xcls, int(max_stages), stages)
