@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kThreads) void k_class_pull_sum(int64_t N, const fl
 template <int H>
 __global__ __launch_bounds__(kThreads) void k_seg_sum(int64_t n_seg, const int32_t* seg_ptr, const int32_t* items, const float* direct,
                                                      const float* agg, const int32_t* ptr, const int32_t* idx, const int32_t* out_row, float* out) {
-    constexpr int LPR = H / 4, U = 4, D = 2;
+    constexpr int LPR = H / 4, U = 2, D = 2;
     const int lr = threadIdx.x % LPR;
     const int64_t stride = (int64_t)gridDim.x * (kThreads / LPR);
     for (int64_t s = (int64_t)blockIdx.x * (kThreads / LPR) + threadIdx.x / LPR; s < n_seg; s += stride) {
