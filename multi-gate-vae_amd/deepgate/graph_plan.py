@@ -374,8 +374,11 @@ class GraphPlan:
         if presorted is not None:            # (items already sorted by colour, members per colour)
             order, counts = presorted[0].to(torch.int32).contiguous(), presorted[1]
         else:
-            order = torch.sort(cid.long(), stable=True).indices.to(torch.int32).contiguous()
-            counts = torch.bincount(cid.long(), minlength=C)
+            srt = torch.sort(cid.long(), stable=True)
+            order = srt.indices.to(torch.int32).contiguous()
+            # members per colour from the sorted run boundaries (a histogram with atomics costs ~1 ms on 2.7 M entries, this 30 us)
+            bounds = torch.searchsorted(srt.values, torch.arange(C + 1, **i64))
+            counts = bounds[1:] - bounds[:-1]
         levels = []
         gid = torch.arange(C, **i64)         # the colours still being summed
         base, src_row = C, 0
