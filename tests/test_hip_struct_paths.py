@@ -179,3 +179,68 @@ def test_segment_sums_against_float64():
     plain = ops._seg_sums(H, levels, order, direct)
     ref2 = torch.zeros(C, H, dtype=torch.float64, device=dev).index_add_(0, cid.long(), direct.double())
     assert float((plain.double() - ref2).abs().max()) <= 2e-5 * float(ref2.abs().max())
+
+
+@pytest.mark.parametrize('H', [64, 32])
+def test_every_half_round_on_colours_for_a_regular_netlist(H):
+    """A batch of 70 identical balanced AND trees (256 leaves each, an inverter behind every gate of alternate levels): the colours stay a few dozen through
+    all four half rounds, so EVERY half round of both encoders is a quotient stage and the expansion to N rows happens once, at the
+    end; against the per-node path, and bit-identical twice."""
+    dev = _dev()
+    import deepgate
+    from deepgate import ops
+    from deepgate.graph_plan import GraphPlan
+    src, dst, gate = [], [], []
+    leaves, per = 256, None
+    # one tree: nodes 0..255 inputs, then level by level: AND of two children, every second level followed by an inverter per node
+    def tree(base):
+        ids = list(range(base, base + leaves))
+        g = [0] * leaves
+        nxt = base + leaves
+        lvl = 0
+        while len(ids) > 1:
+            new = []
+            for a, b in zip(ids[0::2], ids[1::2]):
+                src.extend([a, b]); dst.extend([nxt, nxt]); g.append(1); v = nxt; nxt += 1
+                if lvl % 2 == 1:
+                    src.append(v); dst.append(nxt); g.append(2); v = nxt; nxt += 1
+                new.append(v)
+            ids, lvl = new, lvl + 1
+        return g, nxt
+    base = 0
+    for _ in range(70):
+        g, base = tree(base)
+        gate.extend(g)
+    n = base
+    assert n >= GraphPlan.QUOTIENT_MIN_NODES
+    ei = torch.tensor([src, dst], dtype=torch.int64, device=dev)
+    x = torch.zeros(n, 6, device=dev)
+    x[torch.arange(n, device=dev), torch.tensor(gate, device=dev)] = 1.0
+    plan = GraphPlan(ei, n)
+    quot = plan.quotient(x[:, 1].to(torch.uint8).contiguous(), 4)
+    assert len(quot) == 4 and quot[-1]['C'] <= 64, [s['C'] for s in quot]
+    res = {}
+    for flag in (True, False, True):
+        old = ops.QUOTIENT
+        ops.QUOTIENT = flag
+        try:
+            torch.manual_seed(11)
+            enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=H, s_rounds=2, t_rounds=2, layernorm=True).to(dev)
+            s, t = enc(x, x, ei)
+            gs = torch.randn(n, H, device=dev, generator=torch.Generator(dev).manual_seed(5))
+            gt = torch.randn(n, H, device=dev, generator=torch.Generator(dev).manual_seed(6))
+            ((s * gs).sum() + (t * gt).sum()).backward()
+            out = [s.detach(), t.detach()] + [p.grad.detach().clone() for p in enc.parameters()]
+            if flag and flag in res:
+                if H == 64:      # (the H = 32 backward adds its weight gradients with float atomics)
+                    assert all(torch.equal(a, b) for a, b in zip(out, res[True]))
+            else:
+                res[flag] = out
+            names = ['s', 't'] + [k for k, _ in enc.named_parameters()]
+        finally:
+            ops.QUOTIENT = old
+    for nm, a, b in zip(names, res[True], res[False]):
+        scale = float(b.abs().max())
+        if scale > 1e-6:
+            tol = 2e-5 if nm in ('s', 't') else 1e-4
+            assert float((a - b).abs().max()) <= tol * scale, (nm, float((a - b).abs().max()) / scale)
