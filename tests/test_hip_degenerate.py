@@ -167,3 +167,29 @@ def test_ragged_batch_with_scattered_ids(ctype):
     big = hand_graph(ctype, 100, random_gates(ctype, 100, 2400, seed=12, local=True), seed=12)
     mid = hand_graph(ctype, 10, random_gates(ctype, 10, 60, seed=13), seed=13)
     check_step(ctype, [small, big, mid], weights=(1.0, 0.0, 4.0))
+
+
+def test_identical_regular_circuits_all_half_rounds_on_colours():
+    """70 copies of one balanced AND tree with inverters (41,720 nodes: above GraphPlan.QUOTIENT_MIN_NODES): the colours of the structural
+    encoder stay few, so all eight half rounds of both encoders run on one row per colour and the per-node rows exist only behind the
+    last one; losses and every gradient against the oracle, which knows nothing of colours."""
+    gates, ids, nxt, lvl = [], list(range(256)), 256, 0
+    while len(ids) > 1:
+        new = []
+        for a, b in zip(ids[0::2], ids[1::2]):
+            gates.append(('AND', [a, b])); v = nxt; nxt += 1
+            if lvl % 2 == 1:
+                gates.append(('NOT', [v])); v = nxt; nxt += 1
+            new.append(v)
+        ids, lvl = new, lvl + 1
+    graphs = [hand_graph('aig', 256, gates, seed=40 + i) for i in range(70)]
+    import deepgate
+    from deepgate.graph_plan import GraphPlan
+    assert sum(g['num_nodes'] for g in graphs) >= GraphPlan.QUOTIENT_MIN_NODES
+    check_step('aig', graphs, weights=(1.0, 0.0, 4.0), rounds=4)
+    # (that the stages did run on colours)
+    from deepgate import synthetic as syn
+    arrays = syn.collate(graphs)
+    batch = deepgate.CircuitBatch.from_arrays(arrays, device=_dev())
+    plan = GraphPlan(batch.edge_index, batch.x.shape[0])
+    assert len(plan.quotient(batch.x[:, 1].to(torch.uint8).contiguous(), 8)) == 8
