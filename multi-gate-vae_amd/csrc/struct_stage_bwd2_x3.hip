@@ -578,6 +578,7 @@ __global__ __launch_bounds__(256) void k_struct_stage_bwd2_reduce(B2RedArgs a) {
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t < NT) {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.slab) + t;
+#pragma unroll 8
         for (int g = ty; g < a.nwg; g += 4) {
             const f32x4 v = src[(int64_t)g * (B2::SLAB / 4)];
             s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
