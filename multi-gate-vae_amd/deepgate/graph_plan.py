@@ -241,7 +241,7 @@ class GraphPlan:
     QUOTIENT_FRACTION = 2.0    # a half round runs on distinct rows only while they are at most N / 2 (measured: DESIGN.md 4.3)
     QUOTIENT_GROWTH = 8        # colours multiply by at least this per half round (config 2: x50, x226, x48): the next one is not even tried if C * 8 would not qualify
 
-    QUOTIENT_MIN_NODES = 16384   # below: a step is launch-bound, the extra small launches cost more than the rows save
+    QUOTIENT_MIN_NODES = 131072  # below: a step is launch-bound, the extra small launches cost more than the rows save (65,536 nodes: 7.40 ms with, 7.18 without; 262,144: 10.8 / 11.3)
 
     def quotient(self, xcls, max_stages):
         """Quotient stages of the structural encoder.  Every node starts from the same state (ones, digae_layer.py:260), so after

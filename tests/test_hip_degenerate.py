@@ -170,7 +170,7 @@ def test_ragged_batch_with_scattered_ids(ctype):
 
 
 def test_identical_regular_circuits_all_half_rounds_on_colours():
-    """70 copies of one balanced AND tree with inverters (41,720 nodes: above GraphPlan.QUOTIENT_MIN_NODES): the colours of the structural
+    """70 copies of one balanced AND tree with inverters (41,720 nodes: above the 16,384 the tests switch the quotient stages on from): the colours of the structural
     encoder stay few, so all eight half rounds of both encoders run on one row per colour and the per-node rows exist only behind the
     last one; losses and every gradient against the oracle, which knows nothing of colours."""
     gates, ids, nxt, lvl = [], list(range(256)), 256, 0

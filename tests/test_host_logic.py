@@ -335,3 +335,23 @@ def test_quotient_colours_equal_brute_force_refinement(ctype):
             buf[r] = sum(src[m] for m in range(sp[s_], sp[s_ + 1]))
     assert all(v is not None for v in buf)
     assert buf[:C] == torch.bincount(cid.long(), minlength=C).tolist()
+
+
+def test_quotient_stages_only_from_the_break_even_batch_size():
+    """Below GraphPlan.QUOTIENT_MIN_NODES nodes no quotient stage is built (measured break-even: between 65,536 and 262,144 nodes)."""
+    from deepgate.graph_plan import GraphPlan
+    import deepgate.graph_plan as gp
+    import importlib
+    src = open(gp.__file__).read()
+    assert 'QUOTIENT_MIN_NODES = 131072' in src              # (the session fixture lowers it for the tests: the shipped default)
+    old = GraphPlan.QUOTIENT_MIN_NODES
+    try:
+        GraphPlan.QUOTIENT_MIN_NODES = 10 ** 9
+        g = torch.Generator().manual_seed(1)
+        n = 500
+        src_n = torch.randint(0, n - 1, (900,), generator=g)
+        dst_n = torch.minimum(src_n + 1 + torch.randint(0, 50, (900,), generator=g), torch.tensor(n - 1))
+        plan = GraphPlan(torch.stack([src_n, dst_n]), n)
+        assert plan.quotient(torch.zeros(n, dtype=torch.uint8), 4) == []
+    finally:
+        GraphPlan.QUOTIENT_MIN_NODES = old
