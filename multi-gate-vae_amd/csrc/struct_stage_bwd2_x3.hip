@@ -16,6 +16,8 @@
 //     five workgroup barriers per tile (was twelve), one of them behind the row gather; outputs leave straight from the accumulators.
 //   * parameter gradients leave through per-workgroup slabs and a fixed-order reduction kernel: no float atomics,
 //     bit-identical from run to run.
+#include <cstddef>
+#include <type_traits>
 #include "struct_stage_x3_common.h"
 #ifndef MGV_BWD2_D
 #define MGV_BWD2_D 3            // neighbour slots per row and gather round (2 x 3 x 2 row loads in flight per lane; 2: 1-2 % slower, same box)
@@ -77,12 +79,16 @@ struct B2Args {
 // every phase of the tile loop: the ~20 pointers and sizes the loop touches then live in scalar registers for one phase each instead
 // of for the whole kernel, where half of them were spilled to vector-register lanes and came back through v_readlane in the vector
 // pipe (54 spilled SGPRs, ~110 v_readlane / v_writelane per tile and wave).
+// kargs_now() assumes the by-value B2Args is the kernel's ONLY parameter (kernarg offset 0, host layout) with StageX3Args first
+static_assert(offsetof(B2Args, s) == 0 && std::is_trivially_copyable<B2Args>::value && alignof(B2Args) <= 16, "kargs_now(): B2Args layout");
 __device__ __forceinline__ const StageX3Args& kargs_now() {
     const B2Args __attribute__((address_space(4)))* p = (const B2Args __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
     return ((const B2Args*)p)->s;
 }
 
+__global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args);
+static_assert(std::is_same<decltype(&k_struct_stage_bwd2_x3), void (*)(B2Args)>::value, "kargs_now(): single by-value B2Args parameter");
 __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args) {
     const StageX3Args& a = args.s;
     constexpr int H = B2::H, LDP = B2::LDP, LDF = B2::LDF, BLK = 3 * H * H, PE = kTileRows * B2::LDP;   // PE: elements of one plane
@@ -690,3 +696,8 @@ extern "C" int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, con
     mgv::launch_heavy_sums<64>(a, heavy_n, heavy_nodes, heavy_ws, gy_agg != nullptr, static_cast<hipStream_t>(stream));
     return mgv::launch_bwd2_x3(a, workspace, workspace_floats, static_cast<hipStream_t>(stream));
 }
+
+#if MGV_ABL != 0
+// marker of a timing-ablation build (wrong results by design): deepgate/_hip.py refuses a library that exports it
+extern "C" int mgv_diag_ablation_build(void) { return MGV_ABL; }
+#endif

@@ -735,3 +735,8 @@ extern "C" int mgv_struct_stage_bwd_x3(int H, int64_t N, const float* h_in, cons
         default: return MGV_EUNSUPPORTED;
     }
 }
+
+#if MGV_ABLF != 0
+// marker of a timing-ablation build (wrong results by design): deepgate/_hip.py refuses a library that exports it
+extern "C" int mgv_diag_ablation_build_fwd(void) { return MGV_ABLF; }
+#endif

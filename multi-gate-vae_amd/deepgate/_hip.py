@@ -63,6 +63,11 @@ def load():
         raise HipLibraryError('%s not found: build it with `make -C %s` (or __graft_entry__.build()); '
                               'there is no CPU fallback for the DG_AE hot path' % (LIB_PATH, os.path.dirname(LIB_PATH)))
     lib = ctypes.CDLL(LIB_PATH)
+    for marker in ('mgv_diag_ablation_build', 'mgv_diag_ablation_build_fwd'):
+        # timing-ablation builds of the struct-stage kernels (-DMGV_ABL / -DMGV_ABLF, tools/run_abl*.sh) give wrong results by design
+        if hasattr(lib, marker) and os.environ.get('MGV_ALLOW_ABLATION', '0') != '1':
+            raise HipLibraryError('%s is a timing-ablation build (%s): refused outside tools/ (set MGV_ALLOW_ABLATION=1 for a timing run)'
+                                  % (LIB_PATH, marker))
     sigs = parse_header()
     for name, types in sigs.items():
         try:

@@ -3,6 +3,8 @@
 per-gate-type attention + GRU sweep -> (hs, hf); readout, reconstruction loss, checkpoint loading.
 Sub-module names and construction order follow the reference so state_dicts and seeded
 initialisation line up."""
+import os
+
 import torch
 from torch import nn
 

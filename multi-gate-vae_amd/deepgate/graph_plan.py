@@ -142,8 +142,11 @@ class GraphPlan:
         if self.has_levels:
             self.heavy_segments(True, inactive_only=True)
             self.heavy_segments(True, active_by_level=True)
-        if xcls is not None and self.N > 0 and quotient_stages and self.quotient(xcls, quotient_stages):
-            return self                      # the quotient stages replace the first-stage table and its tagged lists
+        from . import ops
+        counts = sorted({int(c) for c in (quotient_stages if isinstance(quotient_stages, (tuple, list, set)) else [quotient_stages]) if int(c) > 0})
+        if xcls is not None and self.N > 0 and counts and ops.QUOTIENT:
+            if all([len(self.quotient(xcls, c)) > 0 for c in counts]):
+                return self                  # the quotient stages replace the first-stage table and its tagged lists
         if xcls is not None and self.N > 0:
             first = self.first_stage_classes(xcls)
             if first is not None and first[1] <= 256 and self.N < (1 << 24):
@@ -262,9 +265,11 @@ class GraphPlan:
         colour, class and degree) and then CHECKED exactly: every member against its colour's representative, list entry by list
         entry (lists sorted by colour); refinement stops at the first disagreement, so a key collision costs speed, never
         correctness.  Cached per xcls tensor."""
-        hit = getattr(self, '_quotient', None)
-        if hit is not None and hit[0] is xcls and hit[1] == int(max_stages):      # (the tensor itself: an address can be reused)
-            return hit[2]
+        cache = getattr(self, '_quotient', None)
+        if cache is None or cache[0] is not xcls:      # (the tensor itself: an address can be reused)
+            cache = self._quotient = (xcls, {})
+        if int(max_stages) in cache[1]:                 # per stage count: the source and the target encoder may ask for different ones
+            return cache[1][int(max_stages)]
         N, dev = self.N, self.device
         stages = []
         self._check_status()                 # (edge ids outside [0, N) raise here, before the lists are read)
@@ -359,7 +364,7 @@ class GraphPlan:
                     break                    # colours multiply per half round: the next one would not qualify
             if stages:
                 stages[-1]['sum_levels'] = self.class_sum_levels(stages[-1]['cid'], stages[-1]['C'], presorted=last_sorted)
-        self._quotient = (xcls, int(max_stages), stages)
+        cache[1][int(max_stages)] = stages
         return stages
 
     def class_sum_levels(self, cid, C, seg=64, presorted=None):

@@ -72,6 +72,13 @@ class FlatAdam(torch.optim.Optimizer):
         """Gradients are dropped, not zeroed: autograd then ASSIGNS every parameter's gradient instead of adding it to a zero-filled
         view (one small add kernel per parameter and step, 75 at the BASELINE models); `reduce_gradients` gathers them into the
         flat buffer with one multi-tensor copy."""
+        if not set_to_none:
+            if not self._is_flat():
+                self._flatten()
+            self._flat['grad'].zero_()
+            for p, off in zip(self._params(), self._flat['offsets']):
+                p.grad = self._flat['grad'][off:off + p.numel()].view(p.shape)
+            return
         for p in self.param_groups[0]['params']:
             p.grad = None
 
@@ -90,6 +97,10 @@ class FlatAdam(torch.optim.Optimizer):
             torch._foreach_copy_(dst, src)
         if dead:
             torch._foreach_zero_(dead)
+        # from here on p.grad IS the flat view (no kernel): after the all-reduce every reader of p.grad (clipping, logging, tests)
+        # sees the exchanged gradient, not this rank's local one
+        for p, off in zip(self._params(), f['offsets']):
+            p.grad = f['grad'][off:off + p.numel()].view(p.shape)
 
     @torch.no_grad()
     def reduce_gradients(self):

@@ -104,11 +104,13 @@ class BatchPrefetcher:
         self.chunks = iter(chunks)
         self.device = torch.device(device)
         self.cuda = self.device.type == 'cuda'
+        if self.cuda and self.device.index is None:      # 'cuda': torch.cuda.set_device / Stream need an index
+            self.device = torch.device('cuda', torch.cuda.current_device())
         self.gate_ids = list(gate_ids) if gate_ids is not None else None
         self.workers = max(int(workers), 1)
         self.depth = max(int(depth) if depth is not None else self.workers + 1, self.workers)
         self.keys = [k for k in _KEYS if k not in skip]
-        self.quotient_stages = int(quotient_stages)
+        self.quotient_stages = quotient_stages if isinstance(quotient_stages, (tuple, list, set)) else int(quotient_stages)
         self._free = queue.Queue()
         for _ in range(self.depth + 1):
             self._free.put(_Staging(self.cuda))

@@ -211,10 +211,10 @@ class Trainer():
         return loss_status
 
     def _encoder_half_rounds(self):
-        """2 x rounds of the model's structural encoder (what GraphPlan.quotient is asked for), 8 when it cannot be told."""
+        """2 x rounds of the model's two structural encoders (what GraphPlan.quotient is asked for; a list), 8 when it cannot be told."""
         enc = getattr(self.model, getattr(self.model, 'ENCODER_ATTR', 'struct_encoder'), None)
-        conv = getattr(enc, 'source_conv', None)
-        return 2 * int(getattr(conv, 'num_rounds', 4))
+        counts = {2 * int(getattr(getattr(enc, a, None), 'num_rounds', 4)) for a in ('source_conv', 'target_conv')}
+        return sorted(counts)                # --s_rounds and --t_rounds may differ: both encoders' stage counts are warmed
 
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
@@ -301,19 +301,21 @@ class Trainer():
                 # beside the current step (deepgate/prefetch.py); the reference does `batch.to(device)` inside the loop (trainer.py:223)
                 batches = BatchPrefetcher(loader.chunks(), self.device, gate_ids=[g for _, g in getattr(self.model, 'GATES', [])] or None,
                                           workers=max(self.num_workers, 2), quotient_stages=self._encoder_half_rounds())
-                for iter_id, batch in enumerate(batches):
-                    time_stamp = time.time()
-                    if phase == 'train':
-                        loss_status = self.train_step(batch)
-                    else:
-                        with torch.no_grad():
-                            loss_status = self.run_batch(batch, want_pred=False)
-                    # one small device->host copy per step (3 losses + 4 counters), read one step behind so that the host
-                    # never waits for the step it has just enqueued
-                    account(self.enqueue_metrics(loss_status))
-                    batch_time.update(time.time() - time_stamp)
-                account(self.flush_metrics())
-                batches.close()
+                try:
+                    for iter_id, batch in enumerate(batches):
+                        time_stamp = time.time()
+                        if phase == 'train':
+                            loss_status = self.train_step(batch)
+                        else:
+                            with torch.no_grad():
+                                loss_status = self.run_batch(batch, want_pred=False)
+                        # one small device->host copy per step (3 losses + 4 counters), read one step behind so that the host
+                        # never waits for the step it has just enqueued
+                        account(self.enqueue_metrics(loss_status))
+                        batch_time.update(time.time() - time_stamp)
+                    account(self.flush_metrics())
+                finally:
+                    batches.close()          # also when a step raises: worker threads, pinned staging and in-flight batches go
                 if phase == 'train' and self.model_epoch % 10 == 0 and self.rank == 0:
                     self.save(os.path.join(self.log_dir, 'model_{:}.pth'.format(self.model_epoch)))
                     self.save(os.path.join(self.log_dir, 'model_last.pth'))

@@ -180,15 +180,121 @@ def test_losses_and_every_parameter_gradient_at_baseline_graph_size_match_the_or
             worst = (k, err)
         if err > 2e-4:
             print('   %-46s %.2e of scale %.2e' % (k, err, scale))
-        # ONE rule for every parameter, no name-based exceptions: the deviation is at most 1e-3 of the tensor's own gradient scale
-        # (bf16x3 default; 2e-4 for the exact-fp32 kernels, whose own summation-order noise against the oracle reaches 1.6e-4 at
-        # these sizes), or at most 5e-5 of the largest gradient scale inside the same module.  The second clause is what a tensor
-        # needs whose gradient is a globally cancelling sum two orders of magnitude below its module's other gradients (the
-        # attention-logit vector of a 3-input MAJ aggregator on config 3: 1.25e-3 of its own 2.6e-3 scale = 2e-5 of the module's):
-        # there the ~1e-5 bf16x3 product noise of 4M summands does not average below 1e-3 of the small total.  The per-node
-        # cancellation of that gradient is formed exactly since round 3 (func_level_x3.hip: attn_bwd_row, centred form).
+        # Every parameter: the deviation is at most 1e-3 of the tensor's own gradient scale (bf16x3 default; 2e-4 for the exact-fp32
+        # kernels, whose own summation-order noise against the oracle reaches 1.6e-4 at these sizes).  ONE narrow second clause, for
+        # tensors of an attention aggregator module (aggr_*_func) only: at most 2e-3 of the own scale AND at most 5e-5 of the
+        # largest gradient scale inside that same aggregator.  It is what the attention-logit vector of a 3-input MAJ aggregator
+        # needs on config 3 (a globally cancelling sum two orders of magnitude below its module's other gradients: 1.25e-3 of its
+        # own 2.6e-3 scale = 2e-5 of the module's; the ~1e-5 bf16x3 product noise of 4M summands does not average below 1e-3 of
+        # the small total; the per-node cancellation is formed exactly: func_level_x3.hip attn_bwd_row, centred form).  Every
+        # tensor that passes only through it is printed.
         tol = 2e-4 if ops.PRECISION == 'f32' else 1e-3
-        mod = k.split('.')[0]
-        mod_scale = max(float(p[kk].grad.abs().max()) for kk in p if kk.split('.')[0] == mod and p[kk].grad is not None)
-        assert err <= tol or err * scale <= 5e-5 * mod_scale, 'gradient of %s: %.3g of its scale %.3g (module scale %.3g)' % (k, err, scale, mod_scale)
+        if err > tol:
+            mod = k.split('.')[0]
+            in_aggr = mod.startswith('aggr_') and mod.endswith('_func')
+            mod_scale = max(float(p[kk].grad.abs().max()) for kk in p if kk.split('.')[0] == mod and p[kk].grad is not None)
+            ok2 = in_aggr and err <= 2e-3 and err * scale <= 5e-5 * mod_scale
+            assert ok2, 'gradient of %s: %.3g of its scale %.3g (module scale %.3g)' % (k, err, scale, mod_scale)
+            print('   %s passes through the aggregator-relative clause only: %.3g of its scale, %.3g of the module scale' % (k, err, err * scale / mod_scale))
     print('cfg %d: worst gradient deviation %.2e of scale (%s)' % (cfg, worst[1], worst[0]))
+
+
+def _step_grads(model, tr, batch):
+    tr.optimizer.zero_grad()
+    ls = tr.run_batch(batch, want_pred=False)
+    tr.weighted_loss(ls).backward()
+    torch.cuda.synchronize()
+    losses = np.array([float(ls[k].detach()) for k in ('recon_loss', 'prob_loss', 'func_loss')])
+    grads = {k: q.grad.detach().clone() for k, q in model.named_parameters() if q.grad is not None}
+    return losses, grads
+
+
+@pytest.mark.parametrize('cfg,ctype,nb', [(2, 'aig', 64), (3, 'mig', 64), (5, 'xmg', 16)])
+def test_quotient_stages_on_and_off_at_the_full_baseline_batch(cfg, ctype, nb):
+    """The colour-quotient stages at the size they run at in the bench (4.19 M nodes: four stages, 1.66 M colours at config 2,
+    multi-level segment sums): same model, same batch, fixed negatives, `ops.QUOTIENT` on against off — the three losses to 1e-6
+    relative, every parameter gradient to 1e-4 of its scale, and the quotient path bit-identical on repeat
+    (digae_layer.py:257-277: the rows the stages skip are identical by construction)."""
+    dev = _dev()
+    import deepgate
+    from deepgate import ops, synthetic as syn
+    model = _model(ctype, dev, seed=5).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    tr = deepgate.Trainer(types.SimpleNamespace(model='DG_AE'), model, training_id='fsq', save_dir='/tmp/mgv_fullsize', lr=1e-4,
+                          rc_prob_func_weight=[1.0, 4.0, 4.0], device='cuda:0', batch_size=nb, distributed=False)
+    batch = deepgate.CircuitBatch.from_arrays(syn.make_batch(cfg, batch=nb), device=dev)
+    old = ops.QUOTIENT
+    try:
+        ops.QUOTIENT = True
+        l_on, g_on = _step_grads(model, tr, batch)
+        stages = batch._mgv_plan.quotient(batch._mgv_plan.xcls, 8)
+        assert len(stages) >= 2, 'the quotient stages did not engage at this size'
+        l_on2, g_on2 = _step_grads(model, tr, batch)
+        ops.QUOTIENT = False
+        l_off, g_off = _step_grads(model, tr, batch)
+    finally:
+        ops.QUOTIENT = old
+    assert np.all(np.isfinite(l_on)) and np.all(np.isfinite(l_off))
+    np.testing.assert_allclose(l_on, l_off, rtol=1e-6, atol=1e-7)
+    assert np.array_equal(l_on, l_on2)
+    worst = ('', 0.0)
+    assert set(g_on) == set(g_off)
+    for k in g_on:
+        assert torch.equal(g_on[k], g_on2[k]), 'quotient path not bit-identical on repeat: %s' % k
+        scale = float(g_off[k].abs().max())
+        if scale < 1e-9:
+            continue
+        err = float((g_on[k] - g_off[k]).abs().max()) / scale
+        if err > worst[1]:
+            worst = (k, err)
+        assert err <= 1e-4, (k, err)
+    print('cfg %d: %d quotient stages (%s colours); worst gradient difference on/off %.2e (%s)'
+          % (cfg, len(stages), '/'.join(str(s['C']) for s in stages), worst[1], worst[0]))
+
+
+def test_one_baseline_graph_on_the_product_default_struct_path_matches_the_oracle():
+    """tests/conftest.py switches the quotient stages on from 16,384 nodes for the whole session; the PRODUCT default is 131,072
+    (GraphPlan.QUOTIENT_MIN_NODES), so a single 65,536-node graph takes the first-stage (degree, class) table path there.  This
+    test restores the product threshold for one config-2 graph and checks the three losses (1e-4) and the structural encoder's
+    gradients (1e-3 of scale) against the oracle."""
+    dev = _dev()
+    import deepgate
+    from deepgate import synthetic as syn
+    from deepgate.graph_plan import GraphPlan
+    from oracle import ref_cpu as R
+    arrays = syn.make_batch(2, batch=1)
+    model = _model('aig', dev, seed=4).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tr = deepgate.Trainer(types.SimpleNamespace(model='DG_AE'), model, training_id='fsd', save_dir='/tmp/mgv_fullsize', lr=1e-4,
+                          rc_prob_func_weight=[1.0, 4.0, 4.0], device='cuda:0', batch_size=1, distributed=False)
+    old = GraphPlan.QUOTIENT_MIN_NODES
+    GraphPlan.QUOTIENT_MIN_NODES = 131072
+    try:
+        batch = deepgate.CircuitBatch.from_arrays(arrays, device=dev)
+        ls, grads = _step_grads(model, tr, batch)
+        assert batch._mgv_plan.quotient(batch._mgv_plan.xcls, 8) == []          # the product default path: no quotient stages here
+    finally:
+        GraphPlan.QUOTIENT_MIN_NODES = old
+    torch.set_num_threads(max(1, min(16, len(__import__('os').sched_getaffinity(0)))))
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running_' not in k else v.clone()) for k, v in sd.items()}
+    bn = {k: v.clone() for k, v in p.items() if 'running_' in k}
+    ob = R.batch_from_arrays(lambda k: arrays[k])
+    plan = R.LevelPlan('aig', ob['edge_index'], ob['gate'], ob['forward_level'])
+    ols = R.run_batch(p, 'aig', ob, training=True, bn_state=bn, p_drop=0.0, s_rounds=4, t_rounds=4, plan=plan, fast=True)
+    R.weighted_loss(ols, [1.0, 4.0, 4.0]).backward()
+    for i, k in enumerate(('recon_loss', 'prob_loss', 'func_loss')):
+        assert abs(ls[i] - float(ols[k].detach())) <= 1e-4 * max(1.0, abs(float(ols[k].detach()))), (k, ls[i], float(ols[k].detach()))
+    for k, g in grads.items():
+        if not k.startswith('struct_encoder.') and not k.startswith('hs_linear.'):
+            continue
+        ref = p[k].grad
+        scale = float(ref.abs().max())
+        if scale < 1e-7:
+            continue
+        err = float((g.cpu() - ref).abs().max()) / scale
+        assert err <= 1e-3, (k, err)

@@ -355,3 +355,33 @@ def test_quotient_stages_only_from_the_break_even_batch_size():
         assert plan.quotient(torch.zeros(n, dtype=torch.uint8), 4) == []
     finally:
         GraphPlan.QUOTIENT_MIN_NODES = old
+
+
+def test_load_pretrained_without_shipped_weights_raises_file_not_found():
+    """dg_ae_model_aig.py:157-160: `load_pretrained('')` resolves <package>/pretrained/model.pth and loads it; the weights are
+    absent upstream too (.MISSING_LARGE_BLOBS), so the call ends in torch.load's FileNotFoundError — not a NameError."""
+    enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=6, dim_hidden=16, s_rounds=1, t_rounds=1, layernorm=True)
+    model = deepgate.dg_ae_model_aig.Model(struct_encoder=enc, dim_hidden=16)
+    with pytest.raises(FileNotFoundError):
+        model.load_pretrained('')
+    with pytest.raises(FileNotFoundError):
+        model.load_pretrained('/nonexistent/model.pth')
+
+
+def test_quotient_cache_keeps_both_encoders_stage_counts():
+    """--s_rounds != --t_rounds: the two encoders ask GraphPlan.quotient for different stage counts every step; neither request
+    may evict the other (each rebuild costs sorts and host read-backs)."""
+    g = syn.make_graph('aig', 4096, 16, 5, n_inputs=256)
+    a = syn.collate([g])
+    plan = GraphPlan(torch.from_numpy(a['edge_index']), a['num_nodes'])
+    xcls = torch.from_numpy(a['x'][:, 1]).to(torch.uint8).contiguous()
+    old = GraphPlan.QUOTIENT_MIN_NODES
+    GraphPlan.QUOTIENT_MIN_NODES = 1024
+    try:
+        q2, q4 = plan.quotient(xcls, 2), plan.quotient(xcls, 4)
+        assert plan.quotient(xcls, 2) is q2 and plan.quotient(xcls, 4) is q4
+        assert len(q2) <= 2 and len(q4) >= len(q2)
+        plan.warm(xcls, quotient_stages=[2, 4])
+        assert plan.quotient(xcls, 2) is q2
+    finally:
+        GraphPlan.QUOTIENT_MIN_NODES = old
