@@ -285,6 +285,44 @@ int mgv_sweep_pull_heavy(int H, int K, const int32_t* nodes, const int32_t* node
                          const float* alpha, const float* dsc, const float* dzb, const float* attn_u, float* partial_ws,
                          float* ghs, void* stream);
 
+/* ---- the levelised sweep as ONE persistent kernel per direction (csrc/sweep_persist_x3.hip; replaces the reference's Python level
+ * loop dg_ae_model_aig.py:70-97 and arch/tfmlp.py:38-46 like mgv_func_sweep_*_x3, which launch once per level).  H = 64, round 1.
+ * One 8-wave workgroup per CU, each dedicated to one aggregator slot with that slot's Wvc pack resident in LDS; levels are
+ * separated by an XCD-hierarchical grid barrier (csrc/mgv_gridbar.h); rows other workgroups read are stored write-through; the
+ * backward accumulates dWvc in registers across all levels (no per-node rows for a deferred weight-gradient pass).
+ *   key_tile_ptr[num_levels*T + 1]  DEVICE: tile range of every (level, slot) key (tiles are sorted by level, then slot)
+ *   wg_begin_host[T + 1]            HOST: workgroups [wg_begin[g], wg_begin[g+1]) serve slot g; wg_begin[T] = grid <= CU count
+ *   slot_tile_ptr_host[T + 1]       HOST: tiles per slot (a slot with tiles must own a workgroup)
+ *   sync_ws                         DEVICE: mgv_sweep_persist_sync_bytes() bytes, zeroed by the launcher before every launch
+ *   sticky_status                   DEVICE: one uint32 the CALLER zeroes once; set (never cleared) when a barrier spin gave up
+ * Returns MGV_EUNSUPPORTED (use the per-level launchers) for H != 64, N*2H*4 >= 4 GB, or a grid beyond the CU count.
+ * mgv_sweep_persist_status copies the sticky word back (synchronises the stream): MGV_OK, or 1000 + the give-up code. */
+int mgv_sweep_persist_sync_bytes(void);                                                               /* a size, not a status */
+int mgv_sweep_persist_max_grid(void);                                                                 /* CU count of the current device */
+int mgv_func_sweep_fwd_persist_x3(int H, int64_t N, int T, int num_levels, const int32_t* key_tile_ptr,
+                                  const int32_t* wg_begin_host, const int32_t* slot_tile_ptr_host, const int32_t* order,
+                                  const int32_t* order_span, const int32_t* tile_start, const int32_t* tile_count,
+                                  const int32_t* in_ptr, const int32_t* in_src, const float* hs, float* hf,
+                                  const float* attn_u, const void* wpack_bf16, const float* bvc, const float* bih,
+                                  const float* bhh, void* sync_ws, void* sticky_status, void* stream);
+/* backward: wg_slab >= mgv_sweep_persist_slab_floats(H, grid) floats (one gradient partial row per workgroup, summed per slot in
+ * workgroup order: deterministic); d_attn_u / dWvc / dbvc / dbih / dbhh are ADDED to; ghs is WRITTEN for every node (the pull of the
+ * never-updated nodes follows as in mgv_func_sweep_bwd_x3; skip_inactive_longer_than as there).  The plan must hold no UPDATED gate
+ * with more than 64 consumers (GraphPlan.heavy_segments(True, active_by_level=True) is None): such batches use mgv_func_sweep_bwd_x3. */
+int mgv_sweep_persist_slab_floats(int H, int grid);                                                   /* a size, not a status */
+int mgv_func_sweep_bwd_persist_x3(int H, int64_t N, int T, int num_levels, const int32_t* key_tile_ptr,
+                                  const int32_t* wg_begin_host, const int32_t* slot_tile_ptr_host, const int32_t* order,
+                                  const int32_t* order_span, const int32_t* tile_start, const int32_t* tile_count,
+                                  const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                                  const int32_t* out_dst, const int32_t* out_slot, const uint8_t* gslot, const float* hs,
+                                  const float* hf, const float* attn_u, const void* wpack_bf16, const float* bvc,
+                                  const float* bih, const float* bhh, const float* ghf, float* ghs, float* dzb,
+                                  float* alpha, float* dsc, float* d_attn_u, float* dWvc, float* dbvc, float* dbih,
+                                  float* dbhh, float* wg_slab, int64_t wg_slab_floats, int skip_inactive_longer_than,
+                                  void* sync_ws, void* sticky_status, void* stream);
+int mgv_sweep_persist_status(const void* sticky_status, void* stream);
+
+
 /* ---- inner-product decoder and reconstruction loss (digae_layer.py:26-29, dg_ae_model_aig.py:108-130).
  * s, t: row pointers with common row stride ld (the two halves of hs_decompose's output);
  * edge lists are int64 like the reference's edge_index rows. */

@@ -440,6 +440,7 @@ class GraphPlan:
         self.__dict__.pop('_heavy_seg', None)
         self.__dict__.pop('_tagged', None)
         self.__dict__.pop('_slot_nodes', None)
+        self.__dict__.pop('_persist_roles', None)
 
     def _set_levels_hip(self, gate, forward_level, gate_ids):
         from . import _hip
@@ -490,9 +491,11 @@ class GraphPlan:
         n_s2 = _hip.call_value('mgv_count_sort_scratch_ints', num_tiles, T)
         scratch2 = torch.empty(n_s2, **i32)
         _hip.call('mgv_count_sort_i32', num_tiles, ptr(self.tile_slot), T, ptr(self.slot_tiles), ptr(slot_start), ptr(scratch2), n_s2)
-        host = torch.cat([ltp_dev[:max(L, 1) + 1], slot_start]).tolist()                     # third (last) round trip
+        self.key_tile_ptr = tile_first.clone()               # [L * T + 1]: tile range of every (level, slot) key (persistent sweep)
+        host = torch.cat([ltp_dev[:max(L, 1) + 1], slot_start, self.key_tile_ptr]).tolist()  # third (last) round trip
         self.level_tile_ptr = host[:max(L, 1) + 1]
-        self.slot_tile_ptr = host[max(L, 1) + 1:]
+        self.slot_tile_ptr = host[max(L, 1) + 1:max(L, 1) + 1 + T + 1]
+        self._key_tile_ptr_host = host[max(L, 1) + 1 + T + 1:]
         self.num_tiles, self.n_active, self.num_slots = num_tiles, n_active, T
         self.has_levels = True
         return self
@@ -555,6 +558,11 @@ class GraphPlan:
         stp = torch.zeros(T + 1, dtype=torch.int64, device=dev)
         stp[1:] = torch.cumsum(torch.bincount(t_slot, minlength=T), 0)
         self.slot_tile_ptr = [int(v) for v in stp.tolist()]        # host copy
+        per_key = torch.bincount(t_level * T + t_slot, minlength=max(self.num_levels, 1) * T)
+        ktp = torch.zeros(max(self.num_levels, 1) * T + 1, dtype=torch.int64, device=dev)
+        ktp[1:] = torch.cumsum(per_key, 0)
+        self.key_tile_ptr = ktp.to(torch.int32).contiguous()
+        self._key_tile_ptr_host = [int(v) for v in ktp.tolist()]
         per_level = torch.bincount(t_level, minlength=max(self.num_levels, 1))
         ltp = torch.zeros(max(self.num_levels, 1) + 1, dtype=torch.int64, device=dev)
         ltp[1:] = torch.cumsum(per_level, 0)
@@ -571,6 +579,36 @@ class GraphPlan:
                 setattr(self, k, v.to(device))
         self.device = torch.device(device)
         return self
+
+    def persist_roles(self, max_grid):
+        """Workgroup sets of the persistent sweep kernels (csrc/sweep_persist_x3.hip): wg_begin[T + 1] — workgroups
+        [wg_begin[g], wg_begin[g + 1]) stay with aggregator slot g for the whole sweep.  A slot gets as many workgroups as its
+        widest level has tiles when all slots fit `max_grid` (one tile per workgroup and level), else a share of `max_grid`
+        proportional to its tile total (at least one).  None when the plan has no tiles.  Cached per max_grid."""
+        cache = self.__dict__.setdefault('_persist_roles', {})
+        if max_grid in cache:
+            return cache[max_grid]
+        T, L = self.num_slots, max(self.num_levels, 1)
+        ktp = np.asarray(self._key_tile_ptr_host, dtype=np.int64)
+        cnt = (ktp[1:] - ktp[:-1]).reshape(L, T)
+        tot, widest = cnt.sum(0), cnt.max(0)
+        roles = None
+        if int(tot.sum()) > 0 and max_grid >= int((tot > 0).sum()):
+            if int(widest.sum()) <= max_grid:
+                w = widest.copy()
+            else:
+                share = tot * (max_grid / float(tot.sum()))
+                w = np.minimum(np.maximum(np.floor(share).astype(np.int64), (tot > 0).astype(np.int64)), widest)
+                # hand the remaining workgroups to the slots with the most tiles per workgroup; take back from the richest if over
+                while int(w.sum()) < max_grid and bool((w < widest).any()):
+                    load = np.where(w < widest, tot / np.maximum(w, 1), -1.0)
+                    w[int(np.argmax(load))] += 1
+                while int(w.sum()) > max_grid:
+                    load = np.where(w > 1, tot / np.maximum(w, 1), np.inf)
+                    w[int(np.argmin(load))] -= 1
+            roles = [0] + [int(v) for v in np.cumsum(w)]
+        cache[max_grid] = roles
+        return roles
 
     def slot_nodes(self):
         """Node ids (int64, ascending) of every aggregator slot's updated nodes: what a round >= 2 of the sweep gathers to form

@@ -608,6 +608,49 @@ def _sweep_x3(H):
     return use_x3(H) and os.environ.get('MGV_SWEEP_X3', '1') != '0'
 
 
+# The sweep as ONE persistent kernel per direction (csrc/sweep_persist_x3.hip: slot-dedicated workgroups, weights resident in LDS, XCD
+# grid barrier, in-register weight gradient).  Built, parity-tested and MEASURED in round 4: not faster than the per-level kernels at any
+# batch size (config 2: forward 2.17 vs 2.00 ms, backward 8.2 vs 7.4 ms; one graph: 0.95 / 2.80 vs 1.01 / 2.84 ms), so it is
+# opt-in (MGV_SWEEP_PERSIST=1) and the per-level kernels stay the default.
+PERSIST = os.environ.get('MGV_SWEEP_PERSIST', '0') == '1'
+
+
+def _persist_ws(dev):
+    """(barrier state, sticky status word) of the persistent sweep kernels on `dev`: the launchers zero the first before every
+    launch, the second is zeroed here once and only ever set by a kernel whose barrier gave up (persist_check)."""
+    key = ('persist', str(dev))
+    ws = _WS.get(key)
+    if ws is None:
+        nb = _hip.call_value('mgv_sweep_persist_sync_bytes')
+        ws = _WS[key] = (torch.zeros((nb + 3) // 4, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev),
+                         _hip.call_value('mgv_sweep_persist_max_grid'))
+    return ws
+
+
+def persist_status(dev):
+    """The sticky status word as a device tensor (one int32; the trainer copies it back with the step metrics)."""
+    return _persist_ws(dev)[1][:1]
+
+
+def persist_check(dev=None):
+    """Raise if a persistent sweep kernel on `dev` ever gave up at its grid barrier (synchronises)."""
+    for key, ws in list(_WS.items()):
+        if key[0] == 'persist' and (dev is None or key[1] == str(dev)):
+            code = int(ws[1][0].item())
+            if code != 0:
+                raise HipLibraryError('persistent sweep kernel gave up at its grid barrier (code %d): its results are invalid' % code)
+
+
+def _persist_roles(plan, H, N):
+    """wg_begin (ctypes array) when the persistent sweep kernels serve this plan, else None (-> the per-level kernels)."""
+    if not (PERSIST and H == 64 and plan.num_levels > 2 and N * 2 * H * 4 < (1 << 32) and getattr(plan, 'key_tile_ptr', None) is not None):
+        return None
+    roles = plan.persist_roles(_persist_ws(plan.device)[2])
+    if roles is None:
+        return None
+    return (_hip.ctypes.c_int32 * len(roles))(*roles)
+
+
 class FuncSweepRoundFn(torch.autograd.Function):
     """Round r >= 2 of the functional sweep (dg_ae_model_aig.py:70-97 with num_rounds > 1) on the HIP level kernels (bf16x3 or
     exact fp32, as round 1): hf_new = sweep(hs, hf_prev) where every updated gate's GRU starts from its previous state.
@@ -698,7 +741,14 @@ class FuncSweepFn(torch.autograd.Function):
             _hip.call('mgv_sweep_zero_inactive', H, N, ptr(plan.gslot), ptr(hf))
         else:
             hf = torch.zeros(N, H, dtype=F32, device=hsd.device)
-        if wpack is not None:
+        roles = _persist_roles(plan, H, N) if wpack is not None else None
+        if roles is not None:
+            sync, sticky, _ = _persist_ws(hsd.device)
+            stp = (_hip.ctypes.c_int32 * len(plan.slot_tile_ptr))(*plan.slot_tile_ptr)
+            _hip.call('mgv_func_sweep_fwd_persist_x3', H, N, T, plan.num_levels, ptr(plan.key_tile_ptr), roles, stp, ptr(plan.order),
+                      ptr(plan.order_span), ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd),
+                      ptr(hf), ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]), ptr(sync), ptr(sticky))
+        elif wpack is not None:
             _hip.call('mgv_func_sweep_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.order_span),
                       ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
                       ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]))
@@ -729,6 +779,22 @@ class FuncSweepFn(torch.autograd.Function):
         alpha = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
         dsc = torch.empty(max(plan.E, 1), dtype=F32, device=dev)
         grads = [torch.zeros_like(t) for t in par]
+        roles = _persist_roles(plan, H, N) if ctx.wpack is not None else None
+        if roles is not None and plan.heavy_segments(True, active_by_level=True) is None:
+            sync, sticky, _ = _persist_ws(dev)
+            stp = (_hip.ctypes.c_int32 * len(plan.slot_tile_ptr))(*plan.slot_tile_ptr)
+            hv = plan.heavy_segments(True, inactive_only=True)
+            slab = workspace(_hip.call_value('mgv_sweep_persist_slab_floats', H, roles[T]), dev)
+            _hip.call('mgv_func_sweep_bwd_persist_x3', H, N, T, plan.num_levels, ptr(plan.key_tile_ptr), roles, stp, ptr(plan.order),
+                      ptr(plan.order_span), ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.in_ptr), ptr(plan.in_src),
+                      ptr(plan.out_ptr), ptr(plan.out_dst), ptr(plan.out_slot), ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]),
+                      ptr(ctx.wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]), ptr(ghf), ptr(ghs), ptr(dzb), ptr(alpha), ptr(dsc),
+                      *[ptr(g) for g in grads], ptr(slab), slab.numel(), plan.HEAVY_ROW if hv is not None else 0, ptr(sync), ptr(sticky))
+            if hv is not None:
+                pw = workspace(hv['S'] * H, dev)
+                _hip.call('mgv_sweep_pull_heavy', H, hv['K'], ptr(hv['nodes']), ptr(hv['node_seg_ptr']), hv['S'], ptr(hv['seg_e0']), ptr(hv['seg_e1']),
+                          ptr(plan.out_dst), ptr(plan.out_slot), ptr(plan.gslot), ptr(alpha), ptr(dsc), ptr(dzb), ptr(par[0]), ptr(pw), ptr(ghs))
+            return (None, ghs, *grads)
         if ctx.wpack is not None:
             scratch, stp, hv, ha = _sweep_bwd_prep(plan, T, H, dev)
             _hip.call('mgv_func_sweep_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.order_span),

@@ -80,3 +80,47 @@ def test_sweep_x3_matches_fp32_sweep_on_irregular_graphs(H, T):
     # nodes of the unknown gate type and the inputs keep hf = 0
     idle = torch.from_numpy((gate == 9) | (level == 0)).to(dev)
     assert float(results[0][0][idle].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('T,levels,per', [(5, 9, 75), (2, 40, 200), (3, 3, 10)])
+def test_persistent_sweep_kernels_match_the_per_level_kernels(T, levels, per):
+    """csrc/sweep_persist_x3.hip (one persistent kernel per direction: slot-dedicated workgroups, grid barrier between levels,
+    in-register weight gradient; opt-in, ops.PERSIST) against the per-level kernels on the same irregular graphs: forward
+    bit-identical (same arithmetic in the same order), backward to the rounding of its sums (another summation order of the
+    parameter gradients), its barrier never gave up, and two identical calls give identical bits."""
+    dev = _dev()
+    from deepgate import ops
+    from deepgate.graph_plan import GraphPlan
+    if ops.PRECISION != 'x3':
+        pytest.skip('bf16x3 mode only')
+    H = 64
+    rng = np.random.default_rng(11 + T)
+    ei, gate, level, n = _graph(rng, n_in=40, levels=levels, per=per, T=T, hub_fanout=min(50, levels * per // 2), big_fanin=min(7, 30))
+    plan = GraphPlan(torch.from_numpy(ei).to(dev), n)
+    plan.set_levels(torch.from_numpy(gate).to(dev), torch.from_numpy(level).to(dev), list(range(1, T + 1)))
+    torch.manual_seed(H + T)
+    hs0 = torch.randn(n, H, device=dev)
+    par0 = [torch.randn(T, 2 * H, device=dev) * 0.3, torch.randn(T, 3 * H, 2 * H, device=dev) * 0.15,
+            torch.randn(T, 3 * H, device=dev) * 0.1, torch.randn(T, 3 * H, device=dev) * 0.1, torch.randn(T, 3 * H, device=dev) * 0.1]
+    ghf = torch.randn(n, H, device=dev)
+    results = []
+    old = ops.PERSIST
+    try:
+        for persist in (True, True, False):
+            ops.PERSIST = persist
+            hs = hs0.clone().requires_grad_(True)
+            par = [p.clone().requires_grad_(True) for p in par0]
+            hf = ops.FuncSweepFn.apply(plan, hs, *par)
+            (hf * ghf).sum().backward()
+            results.append([hf.detach()] + [hs.grad] + [p.grad for p in par])
+            ops.persist_check(dev)
+    finally:
+        ops.PERSIST = old
+    assert ops._persist_roles(plan, H, n) is None                       # (switched off again: the product default)
+    names = ['hf', 'd hs', 'd attn_u', 'd Wvc', 'd bvc', 'd bih', 'd bhh']
+    assert torch.equal(results[0][0], results[2][0])                    # forward: bit-identical to the per-level kernels
+    for name, a, b, c in zip(names, *results):
+        assert torch.equal(a, b), name                                  # twice the same: identical bits
+        scale = float(c.abs().max())
+        assert scale > 0, name
+        assert float((a - c).abs().max()) <= 2e-5 * scale, (name, float((a - c).abs().max()), scale)

@@ -385,3 +385,25 @@ def test_quotient_cache_keeps_both_encoders_stage_counts():
         assert plan.quotient(xcls, 2) is q2
     finally:
         GraphPlan.QUOTIENT_MIN_NODES = old
+
+
+def test_persistent_sweep_roles_cover_every_slot_and_fit_the_grid():
+    """GraphPlan.persist_roles: workgroup ranges per aggregator slot of the persistent sweep kernels — monotone, a slot with tiles
+    owns a workgroup, never more workgroups than its widest level has tiles, never more than the grid; small plans get one tile per
+    workgroup and level."""
+    g = [syn.make_graph('xmg', 3000, 20, 31 + i, n_inputs=200) for i in range(3)]
+    a = syn.collate(g)
+    plan = GraphPlan(torch.from_numpy(a['edge_index']), a['num_nodes'])
+    gates = [1, 2, 3, 4, 5]
+    plan.set_levels(torch.from_numpy(a['gate']), torch.from_numpy(a['forward_level']), gates)
+    T, L = len(gates), plan.num_levels
+    ktp = np.asarray(plan._key_tile_ptr_host)
+    assert ktp.shape[0] == L * T + 1 and ktp[-1] == plan.num_tiles and np.array_equal(ktp, plan.key_tile_ptr.numpy())
+    assert np.array_equal(ktp[::T], np.asarray(plan.level_tile_ptr))            # level ranges are the slot ranges' union
+    cnt = (ktp[1:] - ktp[:-1]).reshape(L, T)
+    for grid in (256, 16, T):
+        roles = plan.persist_roles(grid)
+        w = np.diff(np.asarray(roles))
+        assert roles[0] == 0 and roles[-1] <= grid and np.all(w >= (cnt.sum(0) > 0)) and np.all(w <= np.maximum(cnt.max(0), 0))
+    assert np.array_equal(np.diff(np.asarray(plan.persist_roles(256))), cnt.max(0))     # everything fits: one tile per workgroup and level
+    assert plan.persist_roles(T - 1) is None                                    # fewer workgroups than slots with tiles
