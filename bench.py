@@ -253,15 +253,22 @@ def main():
     model.train()
 
     gate_ids = [g for _, g in model.GATES]
+    def build_plan(b):
+        # everything a FRESH batch needs before its first step: CSRs, level tiles, and the per-batch caches of the structural
+        # encoder (colour refinement of the quotient stages, or the first-stage table): what the prefetcher's workers do per batch
+        pl = plan_of(b, gate_ids)
+        pl.warm(pl.xcls, quotient_stages=2 * rounds)
+        return pl
+
     t0 = time.time()
-    plan_of(batch, gate_ids)
+    build_plan(batch)
     torch.cuda.synchronize()
     plan_ms = (time.time() - t0) * 1e3
     # steady state: the same construction on a second, equally shaped batch (allocator and kernels warm)
     b2 = deepgate.CircuitBatch.from_arrays(arrays, device=dev)
     torch.cuda.synchronize()
     t0 = time.time()
-    plan_of(b2, gate_ids)
+    build_plan(b2)
     torch.cuda.synchronize()
     plan_ms_steady = (time.time() - t0) * 1e3
     del b2
@@ -371,7 +378,8 @@ def main():
                                        a.config, ctype, B, cfg['n_nodes'], N, E, cfg['n_levels'], a.neg),
                        'global_batch': world * B, 'parallelism': 'dp%d' % world},
             'plan_ms': plan_ms, 'plan_ms_steady': plan_ms_steady,
-            # the rate a loop over FRESH batches would see: every step also builds its batch plan (CSRs, level tiles) on the device
+            # a loop that built every batch's plan (CSRs, level tiles, colour refinement) SERIALLY in front of its step; the prefetcher
+            # overlaps that with the previous step: value_fresh_batches is the measured loop rate
             'value_with_plan_build': world * B / (elapsed / a.steps + plan_ms_steady * 1e-3),
             'losses': losses, 'roofline': roof,
         }
