@@ -55,6 +55,19 @@ int mgv_struct_stage_bwd(int H, int64_t N, const float* h_in, const int32_t* nbr
                          const float* ln_w, const float* ln_b, float ln_eps, const float* gy_direct,
                          const float* gy_agg, float* g_direct_out, float* g_agg_out, float* dWc, float* dbc,
                          float* dWhh, float* dbhh, float* dxtab, float* dln_w, float* dln_b, void* stream);
+/* general node features (digae_layer.py:257-277 accepts any x [N, F]; the reference Models only ever feed one-hot rows): the same half
+ * round with the GRU's feature term per NODE, xrow[N][3H] = W_ih[:, H:] x_i + b_ih (formed with mgv_linear_fwd), instead of the class
+ * table.  Exact-fp32 kernels, H in {16, 32, 64}.  Backward: d_xrow[N][3H] is ADDED to (the caller sums it over the stages that
+ * share the weights and carries it to W_ih[:, H:], b_ih and x through mgv_linear_*). */
+int mgv_struct_stage_rows_fwd(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
+                              const float* xrow, const float* Wc, const float* bc, const float* Whh, const float* bhh,
+                              const float* ln_w, const float* ln_b, float ln_eps, float* h_out, void* stream);
+int mgv_struct_stage_rows_bwd(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
+                              const float* xrow, const float* Wc, const float* WcT, const float* bc, const float* Whh,
+                              const float* WhhT, const float* bhh, const float* ln_w, const float* ln_b, float ln_eps,
+                              const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
+                              float* dWc, float* dbc, float* dWhh, float* dbhh, float* d_xrow, float* dln_w, float* dln_b,
+                              void* stream);
 
 /* ---- the same half round on bf16x3 split-precision MFMA (hi/lo bf16 planes, three products, fp32
  * accumulate; H in {32, 64}).  wpack_bf16 = eight bf16 blocks of 3H*H elements each:

@@ -353,7 +353,7 @@ extern "C" int mgv_linear_wgrad(int64_t N, const float* X1, int K1, int ld1, con
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int K = K1 + K2;
 #define MGV_WG(MM, KK) if (M == MM && K == KK) return mgv::launch_linear_wgrad<MM, KK>(a, st);
-    MGV_WG(16, 16) MGV_WG(16, 32) MGV_WG(32, 16) MGV_WG(32, 32) MGV_WG(32, 64) MGV_WG(64, 32)
+    MGV_WG(16, 16) MGV_WG(16, 32) MGV_WG(32, 16) MGV_WG(32, 32) MGV_WG(32, 64) MGV_WG(64, 16) MGV_WG(64, 32)
     MGV_WG(64, 64) MGV_WG(64, 128) MGV_WG(128, 64)
 #undef MGV_WG
     return MGV_EUNSUPPORTED;

@@ -505,12 +505,12 @@ __global__ __launch_bounds__(WgradGeom<H>::NT) void k_sweep_wgrad_x3(const float
             bf16x8 bh[G::JTW], bl[G::JTW];
 #pragma unroll
             for (int j = 0; j < G::JTW; ++j) {
-                bh[j] = ldfrag_tr(z_hi, G::LDZ, 32 * ks, (jt0 + j) * 16);
-                bl[j] = ldfrag_tr(z_lo, G::LDZ, 32 * ks, (jt0 + j) * 16);
+                bh[j] = ldfrag_tr2(z_hi, G::LDZ, 32 * ks, (jt0 + j) * 16);
+                bl[j] = ldfrag_tr2(z_lo, G::LDZ, 32 * ks, (jt0 + j) * 16);
             }
 #pragma unroll
             for (int i = 0; i < G::ITW; ++i) {
-                const bf16x8 ah = ldfrag_tr(g_hi, G::LDG, 32 * ks, (it0 + i) * 16), al = ldfrag_tr(g_lo, G::LDG, 32 * ks, (it0 + i) * 16);
+                const bf16x8 ah = ldfrag_tr2(g_hi, G::LDG, 32 * ks, (it0 + i) * 16), al = ldfrag_tr2(g_lo, G::LDG, 32 * ks, (it0 + i) * 16);
 #pragma unroll
                 for (int j = 0; j < G::JTW; ++j) mma_x3(acc[i][j], ah, al, bh[j], bl[j]);
             }

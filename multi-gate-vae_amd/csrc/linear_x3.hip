@@ -213,12 +213,12 @@ __global__ __launch_bounds__(64 * NW) void k_linear_wgrad_x3(LinX3Args a) {
             bf16x8 bh[G::JTW], bl[G::JTW];
 #pragma unroll
             for (int j = 0; j < G::JTW; ++j) {
-                bh[j] = ldfrag_tr(x_hi, G::LDX, 32 * ks, (jt0 + j) * 16);
-                bl[j] = ldfrag_tr(x_lo, G::LDX, 32 * ks, (jt0 + j) * 16);
+                bh[j] = ldfrag_tr2(x_hi, G::LDX, 32 * ks, (jt0 + j) * 16);
+                bl[j] = ldfrag_tr2(x_lo, G::LDX, 32 * ks, (jt0 + j) * 16);
             }
 #pragma unroll
             for (int i = 0; i < G::ITW; ++i) {
-                const bf16x8 ah = ldfrag_tr(g_hi, G::LDG, 32 * ks, (it0 + i) * 16), al = ldfrag_tr(g_lo, G::LDG, 32 * ks, (it0 + i) * 16);
+                const bf16x8 ah = ldfrag_tr2(g_hi, G::LDG, 32 * ks, (it0 + i) * 16), al = ldfrag_tr2(g_lo, G::LDG, 32 * ks, (it0 + i) * 16);
 #pragma unroll
                 for (int j = 0; j < G::JTW; ++j) mma_x3(acc[i][j], ah, al, bh[j], bl[j]);
             }

@@ -56,6 +56,21 @@ __device__ __forceinline__ bf16x8 ldfrag_tr(const __bf16* plane, int ld, int k0,
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
+// The same for MFMAs whose BOTH operands are read this way (weight gradients: dG^T x X^T, k = the tile's rows).  The k-slots of a
+// lane are then free to be ANY rows as long as both operands agree, and the rows are dealt so that each half of the instruction is
+// bank-conflict free: the LDS serves a 64-lane b64 read in two passes of 32 lanes (256 B); with the K + 8 plane rows (4 x odd dwords)
+// the eight rows {8q .. 8q+3 : q = 0, 1} of ldfrag_tr's first pass overlap on 24 banks (every pass takes two cycles:
+// SQ_LDS_BANK_CONFLICT was 42 % of the struct backward's LDS-active cycles, profiles/r04_pmc_mfma.json), while eight rows of equal
+// parity tile the 64 banks exactly.  Lane group q reads rows b + {0, 2, 4, 6} and b + 16 + {0, 2, 4, 6}, b = 8 (q & 1) + (q >> 1):
+// pass one (q = 0, 1) the even rows 0..14, pass two (q = 2, 3) the odd ones; every row of the 32-deep k-step exactly once.
+__device__ __forceinline__ bf16x8 ldfrag_tr2(const __bf16* plane, int ld, int k0, int c0) {
+    const int lane = threadIdx.x & 63, q = lane >> 4, i16 = lane & 15;
+    const __bf16* p = plane + (k0 + 8 * (q & 1) + (q >> 1) + 2 * (i16 >> 2)) * ld + c0 + 4 * (i16 & 3);
+    const bf16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4v*)p);
+    const bf16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4v*)(p + 16 * ld));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
 // bf16 LDS planes: [rows][K] with K+8 elements per row (144-byte rows at K=64: the 16 rows a
 // ds_read_b128 fragment touches start 36 dwords apart, i.e. on distinct 4-bank groups)
 template <int K>

@@ -39,6 +39,10 @@ struct StageArgs {
     float* g_direct_out;     // [N][H] or null (stage input is a constant)
     float* g_agg_out;        // [N][H] or null
     float* dWc; float* dbc; float* dWhh; float* dbhh; float* dxtab; float* dlnw; float* dlnb;
+    // general node features (digae_layer.py:257-277 with any x [N, F]): the GRU's feature term W_ih[:, H:] x_i + b_ih per NODE,
+    // xrow [N][3H], instead of the class table; backward: its gradient d_xrow [N][3H] is ADDED to (one stage after the other)
+    const float* xrow;
+    float* d_xrow;
 };
 
 constexpr int kMaxCls = 8;
@@ -74,7 +78,7 @@ template <int H>
 __device__ __forceinline__ void stage_small_vectors(const StageArgs& a, float* smem) {
     using M = StageSmem<H>;
     const int tid = threadIdx.x;
-    for (int i = tid; i < a.C * 3 * H; i += kThreads) smem[M::off_xtab + i] = a.xtab[i];
+    for (int i = tid; i < a.C * 3 * H; i += kThreads) smem[M::off_xtab + i] = a.xtab ? a.xtab[i] : 0.f;
     for (int i = tid; i < 3 * H; i += kThreads) {
         smem[M::off_bc + i] = a.bc[i];
         smem[M::off_bhh + i] = a.bhh[i];
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void k_struct_stage_fwd(StageArgs a) {
                     acc = add4(acc, add4(v0, v1));
                 }
                 if (e < e1) acc = add4(acc, ld4(a.h_in + (int64_t)a.idx[e] * H + 4 * lr));
-                cls = a.xcls[node];
+                cls = a.xcls ? a.xcls[node] : 0;
             }
             st4(s_agg + row * S::LD + 4 * lr, acc);
             st4(s_hin + row * S::LD + 4 * lr, own);
@@ -197,6 +201,7 @@ __global__ __launch_bounds__(kThreads) void k_struct_stage_fwd(StageArgs a) {
                     const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
                     const float deg = s_deg[row];
                     const float* xt = s_xtab + s_cls[row] * 3 * H;
+                    if (a.xrow) { const int64_t nd = base + row; xt = a.xrow + (nd < a.N ? nd : a.N - 1) * 3 * H; }
                     const float rr = sigmoidf_(ar[i][j][e] + deg * bcr + xt[col] + bhr);
                     const float zz = sigmoidf_(az[i][j][e] + deg * bcz + xt[H + col] + bhz);
                     const float nn = tanhf_(ani[i][j][e] + deg * bcn + xt[2 * H + col] + rr * (anh[i][j][e] + bhn));
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(kThreads) void k_struct_stage_bwd(StageArgs a) {
                 } else {
                     for (int e = e0; e < e1; ++e) acc = add4(acc, ld4(a.h_in + (int64_t)a.idx[e] * H + 4 * lr));
                 }
-                cls = a.xcls[node];
+                cls = a.xcls ? a.xcls[node] : 0;
             }
             st4(s_agg + row * S::LD + 4 * lr, acc);
             st4(s_hin + row * S::LD + 4 * lr, own);
@@ -366,6 +371,7 @@ __global__ __launch_bounds__(kThreads) void k_struct_stage_bwd(StageArgs a) {
                     const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
                     const float deg = s_deg[row];
                     const float* xt = s_xtab + s_cls[row] * 3 * H;
+                    if (a.xrow) { const int64_t nd = base + row; xt = a.xrow + (nd < a.N ? nd : a.N - 1) * 3 * H; }
                     const float rr = sigmoidf_(ar[i][j][e] + deg * bcr + xt[col] + bhr);
                     const float zz = sigmoidf_(az[i][j][e] + deg * bcz + xt[H + col] + bhz);
                     const float ghn = anh[i][j][e] + bhn;
@@ -426,6 +432,10 @@ __global__ __launch_bounds__(kThreads) void k_struct_stage_bwd(StageArgs a) {
                     const float dar = dan * ghn * rr * (1.0f - rr);
                     const float danr = dan * rr;
                     ar[i][j][e] = dar; az[i][j][e] = daz; ani[i][j][e] = dan; anh[i][j][e] = danr;
+                    if (a.d_xrow && base + row < a.N) {          // d(feature term) of this node = the input-side gate gradients
+                        float* dx = a.d_xrow + (base + row) * 3 * H;
+                        dx[col] += dar; dx[H + col] += daz; dx[2 * H + col] += dan;
+                    }
                     dhd[i][j][e] = dh * zz;
                     const float deg = s_deg[row];
                     sb_r += dar; sb_z += daz; sb_ni += dan; sb_nh += danr;
@@ -436,7 +446,7 @@ __global__ __launch_bounds__(kThreads) void k_struct_stage_bwd(StageArgs a) {
             colsum_to_lds<H>(sb_r, s_dbhh + col); colsum_to_lds<H>(sb_z, s_dbhh + H + col); colsum_to_lds<H>(sb_nh, s_dbhh + 2 * H + col);
             colsum_to_lds<H>(sd_r, s_dbc + col); colsum_to_lds<H>(sd_z, s_dbc + H + col); colsum_to_lds<H>(sd_n, s_dbc + 2 * H + col);
             // per feature class: d xtab[c] = sum over rows of class c of dGI
-            for (int c = 0; c < a.C; ++c) {
+            for (int c = 0; c < (a.xrow ? 0 : a.C); ++c) {
                 float tr = 0.f, tz = 0.f, tn = 0.f;
 #pragma unroll
                 for (int i = 0; i < S::RTW; ++i)
@@ -535,7 +545,8 @@ __global__ __launch_bounds__(kThreads) void k_struct_stage_bwd(StageArgs a) {
     }
     __syncthreads();
     for (int i = tid; i < 3 * H; i += kThreads) { atomicAdd(a.dbc + i, s_dbc[i]); atomicAdd(a.dbhh + i, s_dbhh[i]); }
-    for (int i = tid; i < a.C * 3 * H; i += kThreads) atomicAdd(a.dxtab + i, s_dxt[i]);
+    if (!a.xrow)
+        for (int i = tid; i < a.C * 3 * H; i += kThreads) atomicAdd(a.dxtab + i, s_dxt[i]);
     if (has_ln)
         for (int i = tid; i < H; i += kThreads) { atomicAdd(a.dlnw + i, s_dlnw[i]); atomicAdd(a.dlnb + i, s_dlnb[i]); }
 }
@@ -600,6 +611,55 @@ extern "C" int mgv_struct_stage_bwd(int H, int64_t N, const float* h_in, const i
     a.Wc = Wc; a.bc = bc; a.Whh = Whh; a.bhh = bhh; a.lnw = ln_w; a.lnb = ln_b; a.eps = ln_eps;
     a.WcT = WcT; a.WhhT = WhhT; a.gy_direct = gy_direct; a.gy_agg = gy_agg; a.g_direct_out = g_direct_out;
     a.g_agg_out = g_agg_out; a.dWc = dWc; a.dbc = dbc; a.dWhh = dWhh; a.dbhh = dbhh; a.dxtab = dxtab;
+    a.dlnw = dln_w; a.dlnb = dln_b;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (H) {
+        case 16: return mgv::launch_bwd<16>(a, st);
+        case 32: return mgv::launch_bwd<32>(a, st);
+        case 64: return mgv::launch_bwd<64>(a, st);
+        default: return MGV_EUNSUPPORTED;
+    }
+}
+
+// ---- general node features: the same half round with the GRU's feature term per NODE (xrow [N][3H] = W_ih[:, H:] x_i + b_ih, formed by
+// the caller with mgv_linear_fwd) instead of a class table.  Exact fp32 kernels, every width; d_xrow [N][3H] is ADDED to.
+extern "C" int mgv_struct_stage_rows_fwd(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
+                                         const float* xrow, const float* Wc, const float* bc, const float* Whh, const float* bhh,
+                                         const float* ln_w, const float* ln_b, float ln_eps, float* h_out, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xrow && Wc && bc && Whh && bhh && h_out);
+    MGV_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr));
+    if (N == 0) return MGV_OK;
+    MGV_CHECK_ARG(nbr_idx != nullptr);
+    mgv::StageArgs a{};
+    a.N = N; a.h_in = h_in; a.ptr = nbr_ptr; a.idx = nbr_idx; a.C = 1; a.xrow = xrow;
+    a.Wc = Wc; a.bc = bc; a.Whh = Whh; a.bhh = bhh; a.lnw = ln_w; a.lnb = ln_b; a.eps = ln_eps; a.h_out = h_out;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (H) {
+        case 16: return mgv::launch_fwd<16>(a, st);
+        case 32: return mgv::launch_fwd<32>(a, st);
+        case 64: return mgv::launch_fwd<64>(a, st);
+        default: return MGV_EUNSUPPORTED;
+    }
+}
+
+extern "C" int mgv_struct_stage_rows_bwd(int H, int64_t N, const float* h_in, const int32_t* nbr_ptr, const int32_t* nbr_idx,
+                                         const float* xrow, const float* Wc, const float* WcT, const float* bc, const float* Whh,
+                                         const float* WhhT, const float* bhh, const float* ln_w, const float* ln_b, float ln_eps,
+                                         const float* gy_direct, const float* gy_agg, float* g_direct_out, float* g_agg_out,
+                                         float* dWc, float* dbc, float* dWhh, float* dbhh, float* d_xrow, float* dln_w, float* dln_b,
+                                         void* stream) {
+    MGV_CHECK_ARG(N >= 0 && h_in && nbr_ptr && xrow && Wc && WcT && bc && Whh && WhhT && bhh && gy_direct);
+    MGV_CHECK_ARG(dWc && dbc && dWhh && dbhh && d_xrow);
+    MGV_CHECK_ARG((ln_w == nullptr) == (ln_b == nullptr));
+    MGV_CHECK_ARG(ln_w == nullptr || (dln_w && dln_b));
+    MGV_CHECK_ARG((g_direct_out == nullptr) == (g_agg_out == nullptr));
+    if (N == 0) return MGV_OK;
+    MGV_CHECK_ARG(nbr_idx != nullptr);
+    mgv::StageArgs a{};
+    a.N = N; a.h_in = h_in; a.ptr = nbr_ptr; a.idx = nbr_idx; a.C = 1; a.xrow = xrow; a.d_xrow = d_xrow;
+    a.Wc = Wc; a.bc = bc; a.Whh = Whh; a.bhh = bhh; a.lnw = ln_w; a.lnb = ln_b; a.eps = ln_eps;
+    a.WcT = WcT; a.WhhT = WhhT; a.gy_direct = gy_direct; a.gy_agg = gy_agg; a.g_direct_out = g_direct_out;
+    a.g_agg_out = g_agg_out; a.dWc = dWc; a.dbc = dbc; a.dWhh = dWhh; a.dbhh = dbhh; a.dxtab = nullptr;
     a.dlnw = dln_w; a.dlnb = dln_b;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (H) {

@@ -482,17 +482,17 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                 const int k0 = 32 * half;
                 bf16x8 bh[2], bl[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr(x_hi, LDP, k0, (jt0 + j) * 16); bl[j] = ldfrag_tr(x_lo, LDP, k0, (jt0 + j) * 16); }
+                for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr2(x_hi, LDP, k0, (jt0 + j) * 16); bl[j] = ldfrag_tr2(x_lo, LDP, k0, (jt0 + j) * 16); }
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     const int p = g == 2 ? 2 + m : g;
                     const __bf16* ph = s_dg + p * 2 * PE;
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
-                        const bf16x8 ah = ldfrag_tr(ph, LDP, k0, (it0 + i) * 16), al = ldfrag_tr(ph + PE, LDP, k0, (it0 + i) * 16);
+                        const bf16x8 ah = ldfrag_tr2(ph, LDP, k0, (it0 + i) * 16), al = ldfrag_tr2(ph + PE, LDP, k0, (it0 + i) * 16);
 #pragma unroll
                         for (int j = 0; j < 2; ++j) mma_x3(gW[g][i * 2 + j], ah, al, bh[j], bl[j]);
-                        if (i == ig && (g == 2 || g == m)) mma_x3(gX[g == 2 ? 1 : 0], ah, al, ldfrag_tr(xe_hi, XLD, k0, 0), ldfrag_tr(xe_lo, XLD, k0, 0));
+                        if (i == ig && (g == 2 || g == m)) mma_x3(gX[g == 2 ? 1 : 0], ah, al, ldfrag_tr2(xe_hi, XLD, k0, 0), ldfrag_tr2(xe_lo, XLD, k0, 0));
                     }
                 }
             }

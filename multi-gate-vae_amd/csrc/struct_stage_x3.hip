@@ -267,8 +267,8 @@ __device__ __forceinline__ void wgrad_x3(f32x4 (&acc)[WgradX3<H>::TPW], const __
         for (int t = 0; t < W::TPW; ++t) {
             const int tl = W::tile_of(w, t);
             const int it = tl / W::HC, jt = tl % W::HC;
-            const bf16x8 ah = ldfrag_tr(d_hi, LDP, k0, it * 16), al = ldfrag_tr(d_lo, LDP, k0, it * 16);
-            const bf16x8 bh = ldfrag_tr(x_hi, LDP, k0, jt * 16), bl = ldfrag_tr(x_lo, LDP, k0, jt * 16);
+            const bf16x8 ah = ldfrag_tr2(d_hi, LDP, k0, it * 16), al = ldfrag_tr2(d_lo, LDP, k0, it * 16);
+            const bf16x8 bh = ldfrag_tr2(x_hi, LDP, k0, jt * 16), bl = ldfrag_tr2(x_lo, LDP, k0, jt * 16);
             mma_x3(acc[t], ah, al, bh, bl);
         }
     }
@@ -573,8 +573,8 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd_x3(StageX3Args 
                 if (w < H / 16) {          // wave-uniform: gate-column tile w of the bias-type gradients
 #pragma unroll
                     for (int ks = 0; ks < kTileRows / 32; ++ks)
-                        mma_x3(gX[p], ldfrag_tr(ph, LDP, 32 * ks, w * 16), ldfrag_tr(pl, LDP, 32 * ks, w * 16),
-                               ldfrag_tr(xe_hi, XLD, 32 * ks, 0), ldfrag_tr(xe_lo, XLD, 32 * ks, 0));
+                        mma_x3(gX[p], ldfrag_tr2(ph, LDP, 32 * ks, w * 16), ldfrag_tr2(pl, LDP, 32 * ks, w * 16),
+                               ldfrag_tr2(xe_hi, XLD, 32 * ks, 0), ldfrag_tr2(xe_lo, XLD, 32 * ks, 0));
                 }
             }
             STAMP(13);

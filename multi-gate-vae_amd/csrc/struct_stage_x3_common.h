@@ -406,10 +406,10 @@ __device__ __forceinline__ void wgrad_blk_x3(f32x4 (&acc)[4], const __bf16* d_hi
         const int k0 = 32 * kk;
         bf16x8 bh[2], bl[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr(x_hi, LDP, k0, (jt0 + j) * 16); bl[j] = ldfrag_tr(x_lo, LDP, k0, (jt0 + j) * 16); }
+        for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr2(x_hi, LDP, k0, (jt0 + j) * 16); bl[j] = ldfrag_tr2(x_lo, LDP, k0, (jt0 + j) * 16); }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const bf16x8 ah = ldfrag_tr(d_hi, LDP, k0, (it0 + i) * 16), al = ldfrag_tr(d_lo, LDP, k0, (it0 + i) * 16);
+            const bf16x8 ah = ldfrag_tr2(d_hi, LDP, k0, (it0 + i) * 16), al = ldfrag_tr2(d_lo, LDP, k0, (it0 + i) * 16);
 #pragma unroll
             for (int j = 0; j < 2; ++j) mma_x3(acc[i * 2 + j], ah, al, bh[j], bl[j]);
         }

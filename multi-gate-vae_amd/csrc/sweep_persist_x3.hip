@@ -369,10 +369,10 @@ __global__ __launch_bounds__(WGW ? kPBT : kLT, WGW ? 3 : 2) void k_sweep_bwd_per
                 // weight gradient of gate p: both operands read transposed from the row-major planes (k = the tile's 64 rows)
 #pragma unroll
                 for (int ks = 0; ks < kTileRows / 32; ++ks) {
-                    const bf16x8 ah = ldfrag_tr(d_hi, LDGP, 32 * ks, wi * 16), al = ldfrag_tr(d_lo, LDGP, 32 * ks, wi * 16);
+                    const bf16x8 ah = ldfrag_tr2(d_hi, LDGP, 32 * ks, wi * 16), al = ldfrag_tr2(d_lo, LDGP, 32 * ks, wi * 16);
 #pragma unroll
                     for (int jj = 0; jj < 2 * H / 16; ++jj) {
-                        const bf16x8 bh = ldfrag_tr(z_hi, LDZP, 32 * ks, jj * 16), bl = ldfrag_tr(z_lo, LDZP, 32 * ks, jj * 16);
+                        const bf16x8 bh = ldfrag_tr2(z_hi, LDZP, 32 * ks, jj * 16), bl = ldfrag_tr2(z_lo, LDZP, 32 * ks, jj * 16);
                         mma_x3(wacc[p][jj], ah, al, bh, bl);
                     }
                 }
@@ -596,10 +596,10 @@ __global__ __launch_bounds__(WGW ? kPBT : kLT, WGW ? 3 : 2) void k_sweep_bwd_per
                     const int wi = wv & 3, jh = wv >> 2;
 #pragma unroll
                     for (int ks = 0; ks < kTileRows / 32; ++ks) {
-                        const bf16x8 ah = ldfrag_tr(d_hi, LDGP, 32 * ks, wi * 16), al = ldfrag_tr(d_lo, LDGP, 32 * ks, wi * 16);
+                        const bf16x8 ah = ldfrag_tr2(d_hi, LDGP, 32 * ks, wi * 16), al = ldfrag_tr2(d_lo, LDGP, 32 * ks, wi * 16);
 #pragma unroll
                         for (int jj = 0; jj < 4; ++jj) {
-                            const bf16x8 bh = ldfrag_tr(z_hi, LDZP, 32 * ks, (jh * 4 + jj) * 16), bl = ldfrag_tr(z_lo, LDZP, 32 * ks, (jh * 4 + jj) * 16);
+                            const bf16x8 bh = ldfrag_tr2(z_hi, LDZP, 32 * ks, (jh * 4 + jj) * 16), bl = ldfrag_tr2(z_lo, LDZP, 32 * ks, (jh * 4 + jj) * 16);
                             mma_x3(wacc[p][jj], ah, al, bh, bl);
                         }
                     }

@@ -19,8 +19,7 @@ def feature_classes(x):
     rows — the reference always feeds one-hot rows (dg_ae_model_aig.py:59)."""
     rows, inv = torch.unique(x, dim=0, return_inverse=True)
     if rows.shape[0] > MAX_FEATURE_CLASSES:
-        raise NotImplementedError('node features with more than %d distinct rows are not supported by the '
-                                  'HIP structural encoder (got %d)' % (MAX_FEATURE_CLASSES, rows.shape[0]))
+        return None                          # general features: MultiGCNEncoder.forward forms the term per node (_forward_rows)
     return rows.to(torch.float32), inv.to(torch.uint8).contiguous()
 
 
@@ -62,12 +61,35 @@ class MultiGCNEncoder(nn.Module):
         xtab = feat_rows @ w_ih[:, H:].t() + gru.bias_ih_l0
         return xtab, Wc, bc, gru.weight_hh_l0, gru.bias_hh_l0
 
+    def _forward_rows(self, x, edge_index, plan):
+        """General node features (more distinct rows than the class table holds; digae_layer.py:257-277 takes any x [N, F]): the GRU's
+        feature term W_ih[:, H:] x_i + b_ih per node through the linear kernels (x zero-padded to their 16-column granule), every
+        half round per node on the exact-fp32 stage kernels (ops.StructEncoderRowsFn)."""
+        H, F_ = self.dim_hidden, self.dim_feature
+        if plan is None:
+            plan = GraphPlan(edge_index, x.shape[0])
+        pad = (-F_) % 16
+        xp = torch.nn.functional.pad(x.to(torch.float32), (0, pad)).contiguous()
+        args = []
+        for aggr, gru in ((self.aggr, self.update), (self.aggr_r, self.update_r)):
+            w_ih = gru.weight_ih_l0
+            w_m = w_ih[:, :H]
+            w_x = torch.nn.functional.pad(w_ih[:, H:], (0, pad))
+            # one Linear per gate block (the linear kernels serve M = H outputs, not 3H), side by side
+            xrow = torch.cat([ops.linear(xp, w_x[g * H:(g + 1) * H], gru.bias_ih_l0[g * H:(g + 1) * H]) for g in range(3)], dim=1)
+            args += [xrow, w_m @ aggr.msg.weight, w_m @ aggr.msg.bias, gru.weight_hh_l0, gru.bias_hh_l0]
+        ln_w = self.ln.weight if self.layernorm else None
+        ln_b = self.ln.bias if self.layernorm else None
+        return ops.StructEncoderRowsFn.apply(plan, self.num_rounds, *args, ln_w, ln_b)
+
     def forward(self, x, edge_index, plan=None, classes=None):
         """`classes` = (distinct feature rows [C,F], row id per node uint8 [N]) may stand in for x."""
         if classes is None:
             if x.shape[1] != self.dim_feature:
                 raise ValueError('expected %d node features, got %d' % (self.dim_feature, x.shape[1]))
             classes = feature_classes(x)
+        if classes is None:
+            return self._forward_rows(x, edge_index, plan)
         rows, xcls = classes
         if rows.shape[1] != self.dim_feature:
             raise ValueError('expected %d node features, got %d' % (self.dim_feature, rows.shape[1]))
@@ -88,8 +110,9 @@ class DirectMultiGCNEncoder(nn.Module):
         self.target_conv = MultiGCNEncoder(t_rounds, dim_hidden, dim_feature, enable_reverse, layernorm)
 
     def forward(self, s, t, edge_index, plan=None, classes=None):
-        cs = classes if classes is not None else feature_classes(s)
         if plan is None:
-            plan = GraphPlan(edge_index, cs[1].shape[0])
+            plan = GraphPlan(edge_index, s.shape[0])
+        cs = classes if classes is not None else feature_classes(s)
         ct = cs if (classes is not None or t is s) else feature_classes(t)
+        # (None: more distinct feature rows than the class table holds -> the per-node feature path of MultiGCNEncoder)
         return self.source_conv(s, edge_index, plan, cs), self.target_conv(t, edge_index, plan, ct)

@@ -404,6 +404,64 @@ class StructEncoderFn(torch.autograd.Function):
                 r['dxtab'], r['dWc'], r['dbc'], r['dWhh'], r['dbhh'], dlw, dlb)
 
 
+class StructEncoderRowsFn(torch.autograd.Function):
+    """MultiGCNEncoder (digae_layer.py:257-277) for GENERAL node features: x has more distinct rows than the class table holds, so
+    the GRU's feature term enters per node — xrow_f / xrow_r [N, 3H] = x W_ih[:, H:]^T + b_ih of the forward / reversed half, formed
+    by the caller with ops.linear (autograd carries their gradients to W_ih, b_ih and x through the linear kernels).  Every half
+    round runs per node on the exact-fp32 stage kernels (mgv_struct_stage_rows_fwd / _bwd): rows differ node by node, so neither
+    the (degree, class) table nor the colour quotient applies.  The reference's Models never reach this path (they feed one-hot
+    rows, dg_ae_model_aig.py:59); it completes the encoder's surface."""
+
+    @staticmethod
+    def forward(ctx, plan, rounds, xrow_f, Wc_f, bc_f, Whh_f, bhh_f, xrow_r, Wc_r, bc_r, Whh_r, bhh_r, ln_w, ln_b):
+        N, H, dev = plan.N, Whh_f.shape[1], Whh_f.device
+        par = [check(t.detach().contiguous(), F32, 'encoder parameter') for t in (xrow_f, Wc_f, bc_f, Whh_f, bhh_f, xrow_r, Wc_r, bc_r, Whh_r, bhh_r)]
+        lw = ln_w.detach().contiguous() if ln_w is not None else None
+        lb = ln_b.detach().contiguous() if ln_b is not None else None
+        assert par[0].shape == (N, 3 * H) and par[5].shape == (N, 3 * H)
+        h = torch.ones(N, H, dtype=F32, device=dev)
+        states = []
+        for _ in range(rounds):
+            for rev in (False, True):
+                p, i = plan.csr(rev)
+                w = par[5:] if rev else par[:5]
+                states.append(h)
+                out = torch.empty(N, H, dtype=F32, device=dev)
+                _hip.call('mgv_struct_stage_rows_fwd', H, N, ptr(h), ptr(p), ptr(i), ptr(w[0]), ptr(w[1]), ptr(w[2]), ptr(w[3]), ptr(w[4]),
+                          ptr(lw), ptr(lb), LN_EPS, ptr(out))
+                h = out
+        ctx.plan, ctx.rounds, ctx.par, ctx.lw, ctx.lb, ctx.states = plan, rounds, par, lw, lb, states
+        return h
+
+    @staticmethod
+    def backward(ctx, gy):
+        plan, par, lw, lb = ctx.plan, ctx.par, ctx.lw, ctx.lb
+        N, H, dev = plan.N, gy.shape[1], gy.device
+        acc = {}
+        for tag, w in (('f', par[:5]), ('r', par[5:])):
+            acc[tag] = [torch.zeros_like(t) for t in w]          # d_xrow, dWc, dbc, dWhh, dbhh
+            acc[tag] += [w[1].t().contiguous(), w[3].t().contiguous()]
+        dlw = torch.zeros_like(lw) if lw is not None else None
+        dlb = torch.zeros_like(lb) if lb is not None else None
+        g_direct, g_agg = gy.contiguous(), None
+        k = len(ctx.states) - 1
+        for _ in range(ctx.rounds):
+            for rev in (True, False):
+                p, i = plan.csr(rev)
+                w = par[5:] if rev else par[:5]
+                g = acc['r' if rev else 'f']
+                gd = torch.empty(N, H, dtype=F32, device=dev) if k > 0 else None
+                ga = torch.empty(N, H, dtype=F32, device=dev) if k > 0 else None
+                _hip.call('mgv_struct_stage_rows_bwd', H, N, ptr(ctx.states[k]), ptr(p), ptr(i), ptr(w[0]), ptr(w[1]), ptr(g[5]), ptr(w[2]),
+                          ptr(w[3]), ptr(g[6]), ptr(w[4]), ptr(lw), ptr(lb), LN_EPS, ptr(g_direct), ptr(g_agg), ptr(gd), ptr(ga),
+                          ptr(g[1]), ptr(g[2]), ptr(g[3]), ptr(g[4]), ptr(g[0]), ptr(dlw), ptr(dlb))
+                g_direct, g_agg = gd, ga
+                k -= 1
+        ctx.states = None
+        f, r = acc['f'], acc['r']
+        return (None, None, f[0], f[1], f[2], f[3], f[4], r[0], r[1], r[2], r[3], r[4], dlw, dlb)
+
+
 # ------------------------------------------------------------------------------------------------
 # Linear over node rows (hs_linear / hs_decompose / VAE heads / readout layers)
 # ------------------------------------------------------------------------------------------------

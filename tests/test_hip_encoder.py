@@ -121,3 +121,43 @@ def test_direct_encoder_module_vs_reference_outputs(name):
     for k, v in enc.named_parameters():
         ref = p[prefix + k].grad
         close(v.grad, ref, rtol=5e-4, atol=5e-5, msg='grad ' + k)
+
+
+@pytest.mark.parametrize('H,F_', [(64, 6), (16, 3)])
+def test_general_node_features_against_the_oracle(H, F_):
+    """digae_layer.py:257-277 takes any x [N, F]; the reference Models only feed one-hot rows.  With random float features (every row
+    distinct) the encoder forms the GRU's feature term per node (MultiGCNEncoder._forward_rows, ops.StructEncoderRowsFn on the
+    exact-fp32 stage kernels): s, t and every parameter gradient — and the gradient of x itself — against oracle/ref_cpu.py."""
+    dev = _dev()
+    import deepgate
+    from deepgate import synthetic as syn
+    from oracle import ref_cpu as R
+    arrays = syn.collate([syn.make_graph('xmg', 60 + 12 * 54, 12, 40 + i, n_inputs=60) for i in range(2)])
+    n = arrays['num_nodes']
+    rng = np.random.Generator(np.random.PCG64(3))
+    x_np = rng.standard_normal((n, F_)).astype(np.float32)
+    ei_np = arrays['edge_index']
+    torch.manual_seed(7)
+    enc = deepgate.digae_layer.DirectMultiGCNEncoder(dim_feature=F_, dim_hidden=H, s_rounds=2, t_rounds=1, layernorm=True)
+    sd = {k: v.clone() for k, v in enc.state_dict().items()}
+    enc = enc.to(dev)
+    x = torch.from_numpy(x_np).to(dev).requires_grad_(True)
+    ei = torch.from_numpy(ei_np).to(dev)
+    assert deepgate.digae_layer.feature_classes(x.detach()) is None          # more distinct rows than the class table holds
+    s, t = enc(x, x, ei)
+    gs = torch.from_numpy(rng.standard_normal((n, H)).astype(np.float32))
+    gt = torch.from_numpy(rng.standard_normal((n, H)).astype(np.float32))
+    ((s * gs.to(dev)).sum() + (t * gt.to(dev)).sum()).backward()
+    p = {'enc.' + k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = torch.from_numpy(x_np).requires_grad_(True)
+    so, to = R.struct_encoder(p, 'enc', xo, torch.from_numpy(ei_np), 2, 1, layernorm=True)
+    ((so * gs).sum() + (to * gt).sum()).backward()
+    for nm, a, b in (('s', s, so), ('t', t, to)):
+        assert float((a.detach().cpu() - b.detach()).abs().max()) <= 2e-4 * max(1.0, float(b.abs().max())), nm
+    named = dict(enc.named_parameters())
+    for k, v in p.items():
+        g, ref = named[k[4:]].grad, v.grad
+        scale = float(ref.abs().max())
+        assert g is not None and scale > 0, k
+        assert float((g.cpu() - ref).abs().max()) <= 1e-3 * scale, (k, float((g.cpu() - ref).abs().max()) / scale)
+    assert float((x.grad.cpu() - xo.grad).abs().max()) <= 1e-3 * float(xo.grad.abs().max())
