@@ -246,7 +246,7 @@ class GraphPlan:
 
     QUOTIENT_MIN_NODES = 131072  # below: a step is launch-bound, the extra small launches cost more than the rows save (65,536 nodes: 7.40 ms with, 7.18 without; 262,144: 10.8 / 11.3)
 
-    def quotient(self, xcls, max_stages):
+    def quotient(self, xcls, max_stages, force=False):
         """Quotient stages of the structural encoder.  Every node starts from the same state (ones, digae_layer.py:260), so after
         half round t a node's row depends only on its colour: (feature class, colour after t-1, multiset of its neighbours' colours
         after t-1) — colour refinement over the alternating in- / out-CSR.  While the colours are few (early half rounds of any
@@ -264,7 +264,8 @@ class GraphPlan:
         Grouping is proposed by a 64-bit key (two sums of random per-colour values over the neighbour list, folded with the own
         colour, class and degree) and then CHECKED exactly: every member against its colour's representative, list entry by list
         entry (lists sorted by colour); refinement stops at the first disagreement, so a key collision costs speed, never
-        correctness.  Cached per xcls tensor."""
+        correctness.  Cached per xcls tensor.  `force`: also below QUOTIENT_MIN_NODES (per-graph parts for assemble_quotient).
+        Every stage also keeps the pieces a batch-level assembly needs under 'raw' (references, no extra work)."""
         cache = getattr(self, '_quotient', None)
         if cache is None or cache[0] is not xcls:      # (the tensor itself: an address can be reused)
             cache = self._quotient = (xcls, {})
@@ -273,7 +274,7 @@ class GraphPlan:
         N, dev = self.N, self.device
         stages = []
         self._check_status()                 # (edge ids outside [0, N) raise here, before the lists are read)
-        if N >= self.QUOTIENT_MIN_NODES and self.E > 0:
+        if (force or N >= self.QUOTIENT_MIN_NODES) and self.E > 0:
             i64 = dict(dtype=torch.int64, device=dev)
             gen = torch.Generator(device=dev)
             gen.manual_seed(0x5EED5)
@@ -350,7 +351,9 @@ class GraphPlan:
                 # mgv_seg_sum (a colour like "AND gate" is named by thousands of entries: balanced, and summed in a fixed order)
                 own_o, own_levels = self.class_sum_levels(own, Cp)
                 ent_o, ent_levels = self.class_sum_levels(ent, Cp)
-                stages.append(dict(C=C, cid=inv.to(torch.int32).contiguous(), rev=rev, ptr=rptr.to(torch.int32).contiguous(),
+                raw = dict(rptr=rptr, ent=ent, own=own, row=row, heavy=heavy, own_sorted=(own_o, own_levels['counts']),
+                           ent_sorted=(ent_o, ent_levels['counts']), cid_sorted=(by_colour, members))
+                stages.append(dict(C=C, raw=raw, cid=inv.to(torch.int32).contiguous(), rev=rev, ptr=rptr.to(torch.int32).contiguous(),
                                    idx=(ent + C).to(torch.int32).contiguous() if n_ent else torch.zeros(1, dtype=torch.int32, device=dev),
                                    ent_idx=ent.to(torch.int32).contiguous() if n_ent else torch.zeros(1, dtype=torch.int32, device=dev),
                                    own=own, own32=own.to(torch.int32).contiguous(), xcls=xcls[rep].contiguous(),
@@ -360,12 +363,102 @@ class GraphPlan:
                                    ent_levels=ent_levels))
                 prev, Cp = inv, C
                 last_sorted = (by_colour, members)
-                if C * self.QUOTIENT_GROWTH * self.QUOTIENT_FRACTION > N:
+                if not force and C * self.QUOTIENT_GROWTH * self.QUOTIENT_FRACTION > N:
                     break                    # colours multiply per half round: the next one would not qualify
             if stages:
                 stages[-1]['sum_levels'] = self.class_sum_levels(stages[-1]['cid'], stages[-1]['C'], presorted=last_sorted)
         cache[1][int(max_stages)] = stages
         return stages
+
+    def assemble_quotient(self, parts, node_off, max_stages):
+        """Quotient stages of a BATCH from its graphs' own stages (`parts[g]` = GraphPlan(graph g).quotient(..., force=True), cached by
+        the loader: a dataset's graphs come back every epoch in other batches, their colour refinement need not).  Graphs share
+        nothing, so the disjoint union of their colourings is a valid colouring of the batch (colours are never merged ACROSS graphs:
+        a few more rows than the batch-level refinement finds, the same exactness — the check ran per graph).  Pure index
+        arithmetic: concatenation with offsets (node ids by `node_off`, colour ids by the running sums of the graphs' colour counts;
+        every graph's stage-1 lists name the ONE shared all-ones row) and the segment tables of mgv_seg_sum rebuilt from the
+        concatenated, already colour-sorted orders (class_sum_levels(presorted=...): no sort).  Stages are cut where a graph has
+        none left, or where the batch's colours exceed N / QUOTIENT_FRACTION; nothing below QUOTIENT_MIN_NODES.  Installs the result
+        as this plan's quotient cache for `max_stages` and returns it."""
+        N, dev = self.N, self.device
+        i64 = dict(dtype=torch.int64, device=dev)
+        counts = sorted({int(c) for c in (max_stages if isinstance(max_stages, (tuple, list, set)) else [max_stages]) if int(c) > 0})
+        S = min([len(p) for p in parts] + [max(counts + [0])])
+        G = len(parts)
+        stages = []
+        if N >= self.QUOTIENT_MIN_NODES and self.E > 0:
+            prev_off = [0] * G               # offset of graph g's previous-stage colours (stage 1: the single shared row)
+            Cp = 1
+            for t in range(S):
+                st = [p[t] for p in parts]
+                Cs = [s_['C'] for s_ in st]
+                C = sum(Cs)
+                if C * self.QUOTIENT_FRACTION > N:
+                    break
+                coff = [0] * G
+                for g in range(1, G):
+                    coff[g] = coff[g - 1] + Cs[g - 1]
+                n_ents = [int(s_['raw']['ent'].numel()) for s_ in st]
+                eoff = [0] * G
+                for g in range(1, G):
+                    eoff[g] = eoff[g - 1] + n_ents[g - 1]
+                n_ent = sum(n_ents)
+                n_nodes = [int(node_off[g + 1]) - int(node_off[g]) for g in range(G)]
+
+                def spread(offs, lens, total):
+                    # the per-graph offsets, one per element of the concatenation (ONE launch, no read-back: the size is known here)
+                    return torch.repeat_interleave(torch.tensor(offs, **i64), torch.tensor(lens, **i64), output_size=total)
+
+                def catoff(ts, off_vec):
+                    flat = (torch.cat(ts) if len(ts) > 1 else ts[0]).long()
+                    return flat + off_vec if off_vec is not None else flat
+                by_node_c = spread(coff, n_nodes, N)
+                by_rep_c, by_rep_e = spread(coff, Cs, C), spread(eoff, Cs, C)
+                by_rep_p = spread(prev_off, Cs, C) if t > 0 else None
+                by_ent_c = spread(coff, n_ents, n_ent)
+                by_ent_p = spread(prev_off, n_ents, n_ent) if t > 0 else None
+                cid = catoff([s_['cid'] for s_ in st], by_node_c)
+                rptr = torch.cat([catoff([s_['raw']['rptr'][:-1] for s_ in st], by_rep_e), torch.tensor([n_ent], **i64)])
+                ent = catoff([s_['raw']['ent'] for s_ in st], by_ent_p)
+                own = catoff([s_['raw']['own'] for s_ in st], by_rep_p)
+                row = catoff([s_['raw']['row'] for s_ in st], by_ent_c)
+                n_heavy = [int(s_['raw']['heavy'].numel()) for s_ in st]
+                heavy = catoff([s_['raw']['heavy'] for s_ in st], spread(coff, n_heavy, sum(n_heavy)) if sum(n_heavy) else None).to(torch.int32)
+                if t == 0:
+                    # one previous colour for everybody: every representative / entry belongs to group 0, in index order
+                    own_pre = (torch.arange(C, dtype=torch.int32, device=dev), torch.tensor([C], **i64))
+                    ent_o = torch.arange(n_ent, dtype=torch.int32, device=dev)
+                    ent_pre = (ent_o, torch.tensor([n_ent], **i64))
+                else:
+                    own_pre = (catoff([s_['raw']['own_sorted'][0] for s_ in st], by_rep_c), torch.cat([s_['raw']['own_sorted'][1] for s_ in st]))
+                    ent_o = catoff([s_['raw']['ent_sorted'][0] for s_ in st], spread(eoff, n_ents, n_ent))
+                    ent_pre = (ent_o, torch.cat([s_['raw']['ent_sorted'][1] for s_ in st]))
+                own_o, own_levels = self.class_sum_levels(None, Cp, presorted=own_pre)
+                ent_o, ent_levels = self.class_sum_levels(None, Cp, presorted=ent_pre)
+                zero1 = torch.zeros(1, dtype=torch.int32, device=dev)
+                cid_sorted = (catoff([s_['raw']['cid_sorted'][0] for s_ in st], spread([int(v) for v in node_off[:G]], n_nodes, N)), torch.cat([s_['raw']['cid_sorted'][1] for s_ in st]))
+                stages.append(dict(C=C, cid=cid.to(torch.int32).contiguous(), rev=st[0]['rev'], ptr=rptr.to(torch.int32).contiguous(),
+                                   idx=(ent + C).to(torch.int32).contiguous() if n_ent else zero1,
+                                   ent_idx=ent.to(torch.int32).contiguous() if n_ent else zero1,
+                                   own=own, own32=own.to(torch.int32).contiguous(), xcls=torch.cat([s_['xcls'] for s_ in st]).contiguous(),
+                                   heavy=(int(heavy.numel()), heavy.contiguous()), own_rows=own_o, own_levels=own_levels,
+                                   ent_rows=row[ent_o.long()].to(torch.int32).contiguous() if n_ent else zero1, ent_levels=ent_levels,
+                                   _cid_sorted=cid_sorted))
+                prev_off, Cp = coff, C
+        out = {}
+        for c in counts:
+            lst = list(stages[:c])
+            if lst:
+                last = dict(lst[-1])
+                last['sum_levels'] = self.class_sum_levels(last['cid'], last['C'], presorted=last['_cid_sorted'])
+                lst[-1] = last
+            out[c] = lst
+        xc = getattr(self, 'xcls', None)
+        cache = getattr(self, '_quotient', None)
+        if cache is None or cache[0] is not xc:
+            cache = self._quotient = (xc, {})
+        cache[1].update(out)
+        return out
 
     def class_sum_levels(self, cid, C, seg=64, presorted=None):
         """Segment tables of mgv_seg_sum for per-colour row sums: (order [N] int32 = nodes sorted by colour, tables) with
@@ -385,6 +478,7 @@ class GraphPlan:
             bounds = torch.searchsorted(srt.values, torch.arange(C + 1, **i64))
             counts = bounds[1:] - bounds[:-1]
         levels = []
+        counts0 = counts
         gid = torch.arange(C, **i64)         # the colours still being summed
         base, src_row = C, 0
         while True:
@@ -406,7 +500,7 @@ class GraphPlan:
                 out_row = torch.where(seg_multi, base + torch.cumsum(seg_multi, 0) - 1, gid[cls]).to(torch.int32).contiguous()
             levels.append((total, sp.to(torch.int32).contiguous(), out_row, src_row))
             if n_partial == 0:
-                return order, dict(C=C, rows=base, levels=levels)
+                return order, dict(C=C, rows=base, levels=levels, counts=counts0)
             gid, counts = gid[multi], nseg[multi]
             src_row, base = base, base + n_partial
 

@@ -125,6 +125,56 @@ class BatchPrefetcher:
             s = self._tls.stream = torch.cuda.Stream(self.device)
         return s
 
+    # ---- per-graph colour refinement, cached on the graph (a dataset's graphs come back every epoch, in other batches)
+    PARTS_CACHE_BYTES = 16 << 30         # device bytes of cached per-graph stages; beyond: batches refine their colours themselves
+    # Off by default.  Measured at config 2 (round 4, tools/assemble_probe.py, bench.py): the assembly costs 6.8 ms of device time per batch
+    # against 9.6 for the batch-level refinement, but colours are not merged ACROSS graphs: 192 / 6,000 / 460,531 colours in three stages
+    # instead of 3 / 152 / 34,377 / 1,662,243 in four, so the step itself is ~3 ms slower: fresh-batch loop 76.7 ms against 73.8.
+    PER_GRAPH_QUOTIENT = False
+    _parts_lock = threading.Lock()
+    _parts_bytes = 0
+
+    def _graph_parts(self, graphs, stream):
+        """Every graph's own quotient stages (GraphPlan.quotient(..., force=True) of the single graph), from the cache kept on the graph
+        dict or computed now on this worker's stream; None when the batch cannot use them."""
+        from . import ops
+        from .graph_plan import GraphPlan
+        counts = self.quotient_stages if isinstance(self.quotient_stages, (tuple, list, set)) else [self.quotient_stages]
+        max_st = max([int(c) for c in counts] + [0])
+        if not (self.PER_GRAPH_QUOTIENT and ops.QUOTIENT and max_st > 0 and all(isinstance(g, dict) and 'edge_index' in g and 'x' in g for g in graphs)):
+            return None
+        if sum(int(g['num_nodes']) for g in graphs) < GraphPlan.QUOTIENT_MIN_NODES:
+            return None
+        key = (str(self.device), max_st)
+        parts = []
+        for g in graphs:
+            hit = g.get('_mgv_quot', {}).get(key) if isinstance(g.get('_mgv_quot'), dict) else None
+            if hit is None:
+                with BatchPrefetcher._parts_lock:
+                    hit = g.get('_mgv_quot', {}).get(key) if isinstance(g.get('_mgv_quot'), dict) else None
+                    if hit is None:
+                        if BatchPrefetcher._parts_bytes > self.PARTS_CACHE_BYTES:
+                            return None
+                        n = int(g['num_nodes'])
+                        ei = torch.from_numpy(np.ascontiguousarray(g['edge_index'])).to(self.device, non_blocking=True)
+                        xc = torch.from_numpy(np.ascontiguousarray(np.asarray(g['x'])[:, 1]).astype(np.uint8)).to(self.device, non_blocking=True)
+                        st = GraphPlan(ei, n).quotient(xc, max_st, force=True)
+                        st = [dict(C=s_['C'], cid=s_['cid'], rev=s_['rev'], xcls=s_['xcls'], raw=s_['raw']) for s_ in st]
+                        ev = torch.cuda.Event()
+                        ev.record(stream)
+                        nbytes = 0
+                        for s_ in st:
+                            for v in list(s_['raw'].values()) + [s_['cid'], s_['xcls']]:
+                                for t in (v if isinstance(v, tuple) else (v,)):
+                                    if torch.is_tensor(t):
+                                        nbytes += t.numel() * t.element_size()
+                        BatchPrefetcher._parts_bytes += nbytes
+                        hit = (st, ev)
+                        g.setdefault('_mgv_quot', {})[key] = hit
+            stream.wait_event(hit[1])        # (computed on another worker's stream, possibly)
+            parts.append(hit[0])
+        return parts
+
     def _take_staging(self):
         st = self._free.get()
         if st.event is not None:             # its previous batch's host-to-device copy (long finished by the time the slot comes round)
@@ -155,6 +205,10 @@ class BatchPrefetcher:
             self._free.put(st)
             if self.gate_ids is not None:
                 plan = plan_of(b, self.gate_ids)        # its few host read-backs wait on THIS stream only
+                parts = self._graph_parts(graphs, stream)
+                if parts is not None:
+                    # the batch's quotient stages from its graphs' cached ones: index arithmetic instead of a colour refinement per batch
+                    plan.assemble_quotient(parts, host['graph_ptr'].tolist(), self.quotient_stages)
                 plan.warm(plan.xcls, self.quotient_stages)     # ... and those of the caches the step would build lazily
                 if getattr(b, 'tt_pair_index', None) is not None and b.tt_pair_index.shape[1] >= 2:
                     from . import ops

@@ -407,3 +407,88 @@ def test_persistent_sweep_roles_cover_every_slot_and_fit_the_grid():
         assert roles[0] == 0 and roles[-1] <= grid and np.all(w >= (cnt.sum(0) > 0)) and np.all(w <= np.maximum(cnt.max(0), 0))
     assert np.array_equal(np.diff(np.asarray(plan.persist_roles(256))), cnt.max(0))     # everything fits: one tile per workgroup and level
     assert plan.persist_roles(T - 1) is None                                    # fewer workgroups than slots with tiles
+
+
+def _run_seg_tables(levels, items_value):
+    """Run mgv_seg_sum's tables on one number per item: the buffer of `rows` sums (every row written exactly once)."""
+    buf = [None] * levels['rows']
+    for li, (n_seg, sp, out_row, src_row) in enumerate(levels['levels']):
+        sp = sp.tolist()
+        rows = out_row.tolist() if out_row is not None else list(range(n_seg))
+        assert len(sp) == n_seg + 1 and sp[0] == 0 and all(0 <= b - a_ <= 64 for a_, b in zip(sp[:-1], sp[1:]))
+        src = items_value if li == 0 else buf[src_row:]
+        for s_, r in enumerate(rows):
+            assert buf[r] is None
+            buf[r] = sum(src[m] for m in range(sp[s_], sp[s_ + 1]))
+    assert all(v is not None for v in buf)
+    return buf
+
+
+def test_batch_quotient_assembled_from_per_graph_stages():
+    """GraphPlan.assemble_quotient: a batch's quotient stages put together from its graphs' own (cached) stages by index arithmetic.
+    Per graph the colours equal brute-force colour refinement; colours are never shared between graphs; a representative's list
+    names its neighbours' previous colours in the BATCH numbering; the segment tables (own / ent / final sums) add up."""
+    graphs = [syn.make_graph('xmg', 120 + 25 * 30, 30, 50 + i, n_inputs=120) for i in range(3)]
+    graphs.append(syn.make_graph('xmg', 120 + 25 * 30, 30, 50, n_inputs=120))          # a copy of graph 0: still its own colours
+    a = syn.collate(graphs)
+    N, ei = a['num_nodes'], a['edge_index']
+    node_off = a['graph_ptr'].tolist()
+    old = GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES
+    GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES = 1.3, 1
+    try:
+        parts = []
+        for g in graphs:
+            xc = torch.from_numpy(g['x'][:, 1].astype('uint8'))
+            parts.append(GraphPlan(torch.from_numpy(g['edge_index']), g['num_nodes']).quotient(xc, 3, force=True))
+        plan = GraphPlan(torch.from_numpy(ei), N)
+        plan.xcls = torch.from_numpy(a['x'][:, 1].astype('uint8'))
+        out = plan.assemble_quotient(parts, node_off, [2, 3])
+        assert plan.quotient(plan.xcls, 3) is out[3] and plan.quotient(plan.xcls, 2) is out[2]      # installed as the plan's cache
+    finally:
+        GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES = old
+    q = out[3]
+    assert len(q) >= 2 and len(out[2]) == 2 and 'sum_levels' in out[2][-1] and 'sum_levels' in q[-1]
+    xcls = plan.xcls
+    gid = np.repeat(np.arange(len(graphs)), np.diff(node_off))
+    col = [0] * N
+    for t, s in enumerate(q, start=1):
+        src, dst = (ei[1], ei[0]) if t % 2 == 0 else (ei[0], ei[1])
+        nb = [[] for _ in range(N)]
+        for u, v in zip(src.tolist(), dst.tolist()):
+            nb[v].append(col[u])
+        keys = [(int(gid[i]), int(xcls[i]), col[i], tuple(sorted(nb[i]))) for i in range(N)]      # the graph id is part of the colour
+        ids = {}
+        for kk in keys:
+            ids.setdefault(kk, len(ids))
+        cid = s['cid'].tolist()
+        assert len(set(zip((ids[kk] for kk in keys), cid))) == len(ids) == s['C'], t
+        prev_cid = q[t - 2]['cid'].tolist() if t > 1 else [0] * N
+        Cp = q[t - 2]['C'] if t > 1 else 1
+        first = {}
+        for i, c in enumerate(cid):
+            first.setdefault(c, i)
+        ptr, idx, ent, own, xc = s['ptr'].tolist(), s['idx'].tolist(), s['ent_idx'].tolist(), s['own'].tolist(), s['xcls'].tolist()
+        for c in range(s['C']):
+            members = [i for i in range(N) if cid[i] == c]
+            assert len({(prev_cid[i], int(xcls[i])) for i in members}) == 1 and xc[c] == int(xcls[members[0]]) and own[c] == prev_cid[members[0]]
+            r = members[0]
+            want = sorted(prev_cid[u] for u, v in zip(src.tolist(), dst.tolist()) if v == r)
+            assert sorted(ent[ptr[c]:ptr[c + 1]]) == want and sorted(idx[ptr[c]:ptr[c + 1]]) == [s['C'] + w for w in want], (t, c)
+        # colour-level sums for stage t-1: per previous colour, the representatives that own it / the entries that name it
+        buf = _run_seg_tables(s['own_levels'], [1] * s['C'])
+        assert s['own_levels']['C'] == Cp and sorted(s['own_rows'].tolist()) == list(range(s['C']))
+        assert buf[:Cp] == np.bincount(np.asarray(own), minlength=Cp).tolist()
+        n_ent = ptr[-1]
+        if n_ent:
+            rows_of_entries = s['ent_rows'].tolist()
+            owner = np.repeat(np.arange(s['C']), np.diff(ptr))
+            # ent_rows[k] = the colour whose list holds the k-th entry in previous-colour order: a permutation of the entries' owners
+            assert sorted(rows_of_entries) == sorted(owner.tolist())
+            buf = _run_seg_tables(s['ent_levels'], [1] * n_ent)
+            assert buf[:Cp] == np.bincount(np.asarray(ent[:n_ent]), minlength=Cp).tolist()
+        col = [ids[kk] for kk in keys]
+    for lst in (out[2], out[3]):
+        order, levels = lst[-1]['sum_levels']
+        cidl = lst[-1]['cid']
+        assert sorted(order.tolist()) == list(range(N)) and bool((cidl[order.long()][1:] >= cidl[order.long()][:-1]).all())
+        assert _run_seg_tables(levels, [1] * N)[:lst[-1]['C']] == torch.bincount(cidl.long(), minlength=lst[-1]['C']).tolist()
