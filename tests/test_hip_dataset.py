@@ -174,6 +174,9 @@ def test_prefetched_batches_assemble_their_quotient_stages_from_per_graph_caches
     np.testing.assert_allclose(l_on, l_off, rtol=1e-6, atol=1e-7)
     for k in g_on:
         scale = float(g_off[k].abs().max())
+        if k in ('readout_prob.fc.0.bias', 'readout_prob.fc.4.bias'):
+            # a Linear bias in front of BatchNorm (mlp.py:29-32): the gradient is mathematically zero, both sides hold rounding noise
+            scale = float(g_off[k.replace('bias', 'weight')].abs().max())
         if scale < 1e-9:
             continue
         err = float((g_on[k] - g_off[k]).abs().max()) / scale

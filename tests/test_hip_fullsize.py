@@ -213,7 +213,8 @@ def _step_grads(model, tr, batch):
 def test_quotient_stages_on_and_off_at_the_full_baseline_batch(cfg, ctype, nb):
     """The colour-quotient stages at the size they run at in the bench (4.19 M nodes: four stages, 1.66 M colours at config 2,
     multi-level segment sums): same model, same batch, fixed negatives, `ops.QUOTIENT` on against off — the three losses to 1e-6
-    relative, every parameter gradient to 1e-4 of its scale, and the quotient path bit-identical on repeat
+    relative, every parameter gradient to 1e-4 of its scale (attention logits 1e-3, readout MLP 3e-4: see below), and the quotient
+    path bit-identical on repeat
     (digae_layer.py:257-277: the rows the stages skip are identical by construction)."""
     dev = _dev()
     import deepgate
@@ -244,6 +245,9 @@ def test_quotient_stages_on_and_off_at_the_full_baseline_batch(cfg, ctype, nb):
     for k in g_on:
         assert torch.equal(g_on[k], g_on2[k]), 'quotient path not bit-identical on repeat: %s' % k
         scale = float(g_off[k].abs().max())
+        if k in ('readout_prob.fc.0.bias', 'readout_prob.fc.4.bias'):
+            # a Linear bias in front of BatchNorm (mlp.py:29-32): the gradient is mathematically zero, both sides hold rounding noise
+            scale = float(g_off[k.replace('bias', 'weight')].abs().max())
         if scale < 1e-9:
             continue
         err = float((g_on[k] - g_off[k]).abs().max()) / scale
@@ -253,9 +257,12 @@ def test_quotient_stages_on_and_off_at_the_full_baseline_batch(cfg, ctype, nb):
         # a globally cancelling sum over 4 M nodes that amplifies the ~2e-5 rounding difference of hs between the two encoder paths
         # (measured 2.4e-4 at config 2; the same tensors are the ones the oracle comparison above needs its second clause for)
         logit = k.startswith('aggr_') and ('.attn_lin.' in k or '.msg_k.' in k)
-        if logit and err > 1e-4:
-            print('   %s: %.2e of scale (attention-logit bound 1e-3)' % (k, err))
-        assert err <= (1e-3 if logit else 1e-4), (k, err)
+        # the readout MLP sits behind 2 x 32 x N ReLU decisions (mlp.py:33-36): the ~2e-5 difference of hf flips a handful of them,
+        # each worth ~1/N of the L1 gradient (the smoke test's x3 for the probability loss): 3e-4 (measured 1.03e-4 at config 3)
+        kink = k.startswith('readout_prob.')
+        if (logit or kink) and err > 1e-4:
+            print('   %s: %.2e of scale (%s)' % (k, err, 'attention-logit bound 1e-3' if logit else 'ReLU-kink bound 3e-4'))
+        assert err <= (1e-3 if logit else 3e-4 if kink else 1e-4), (k, err)
     print('cfg %d: %d quotient stages (%s colours); worst gradient difference on/off %.2e (%s)'
           % (cfg, len(stages), '/'.join(str(s['C']) for s in stages), worst[1], worst[0]))
 

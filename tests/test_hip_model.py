@@ -118,6 +118,10 @@ def test_train_step_losses_grads_adam_match_reference(name):
             assert float(np.abs(ref[:, :H]).max()) < 1e-5
             g, ref = g[:, H:], ref[:, H:]
         scale = max(1e-6, float(np.abs(ref).max()))
+        if k in ('readout_prob.fc.0.bias', 'readout_prob.fc.4.bias'):
+            # a Linear bias in front of BatchNorm (mlp.py:29-32): the gradient is mathematically zero, the reference's and ours are the
+            # rounding noise of a column sum (~1e-6, order-dependent); priced against the layer's weight gradient
+            scale = max(scale, float(np.abs(z['grad_' + k.replace('bias', 'weight')]).max()))
         np.testing.assert_allclose(g, ref, rtol=1e-3, atol=grad_atol() * scale + 1e-6, err_msg='grad ' + k)
     if 'after_hs_linear.weight' in z.files:
         tr.optimizer.step()
