@@ -21,6 +21,49 @@ TILE = 64
 NO_GATE = 255
 
 
+class ColourDictionary:
+    """Dataset-wide, EXACT dictionary of colour signatures -> global colour ids, one per half round of the structural encoder.
+    A colour of half round t is (feature class, global colour of its own row after t-1, sorted global colours of its neighbours after
+    t-1); two nodes of different graphs with equal signatures have identical rows after half round t (induction over t: every node
+    starts from ones, digae_layer.py:260), so a batch may compute them once.  Signatures are compared as Python tuples / bytes —
+    no hashing of our own, no collisions.  Filled per graph, once, from the graph's own quotient stages (their representatives'
+    lists): GraphPlan.assemble_quotient then merges the graphs' colours of a batch by their global ids."""
+
+    def __init__(self, max_entries=20000000):
+        self.maps, self.next_id, self.max_entries = [], [], int(max_entries)
+
+    def globals_of(self, stages):
+        """stages: per half round a dict of HOST arrays ptr [C+1], ent [n_ent] (previous colours, the graph's own numbering),
+        own [C], xcls [C].  -> list of int64 arrays: the global id of every colour of the graph, per half round."""
+        out = []
+        gprev = np.zeros(1, dtype=np.int64)                   # before the first half round: one colour, global id 0
+        for t, st in enumerate(stages):
+            while len(self.maps) <= t:
+                self.maps.append({}); self.next_id.append(0)
+            table = self.maps[t]
+            ptr, ent, own, xcls = (np.asarray(st[k]) for k in ('ptr', 'ent', 'own', 'xcls'))
+            C = int(own.shape[0])
+            deg = np.diff(ptr)
+            entg = gprev[ent] if ent.size else np.zeros(0, dtype=np.int64)
+            rowid = np.repeat(np.arange(C), deg)
+            entg = entg[np.lexsort((entg, rowid))] if entg.size else entg      # every list sorted by global colour: a multiset
+            owng = gprev[own]
+            g = np.empty(C, dtype=np.int64)
+            full = len(table) >= self.max_entries
+            for c in range(C):
+                key = (int(xcls[c]), int(owng[c]), entg[ptr[c]:ptr[c + 1]].tobytes())
+                v = table.get(key)
+                if v is None:
+                    v = self.next_id[t]
+                    self.next_id[t] += 1
+                    if not full:
+                        table[key] = v                        # (a full table hands out fresh ids: such colours are simply not shared)
+                g[c] = v
+            out.append(g)
+            gprev = g
+        return out
+
+
 class GraphPlan:
     """in-CSR  : in_ptr[N+1], in_src[E]              sources of each node, original edge order kept
     out-CSR : out_ptr[N+1], out_dst[E], out_slot[E] destinations; out_slot = position of that edge
@@ -310,8 +353,8 @@ class GraphPlan:
                 first[1:] = skey[1:] != skey[:-1]
                 starts = torch.nonzero(first).reshape(-1)
                 C = int(starts.numel())
-                if C * self.QUOTIENT_FRACTION > N:
-                    break
+                if C * (1.1 if force else self.QUOTIENT_FRACTION) > N:
+                    break                    # (force: a graph's own stages go on until it is nearly fully refined; assembly applies the batch rule)
                 inv = torch.empty(N, **i64)
                 inv[by_colour] = torch.cumsum(first, 0) - 1
                 members = torch.diff(starts, append=torch.tensor([N], **i64))
@@ -451,6 +494,83 @@ class GraphPlan:
             if lst:
                 last = dict(lst[-1])
                 last['sum_levels'] = self.class_sum_levels(last['cid'], last['C'], presorted=last['_cid_sorted'])
+                lst[-1] = last
+            out[c] = lst
+        xc = getattr(self, 'xcls', None)
+        cache = getattr(self, '_quotient', None)
+        if cache is None or cache[0] is not xc:
+            cache = self._quotient = (xc, {})
+        cache[1].update(out)
+        return out
+
+    def assemble_quotient_merged(self, parts, gcols, node_off, max_stages):
+        """Like assemble_quotient, but colours are MERGED across the batch's graphs through their dataset-wide global ids
+        (`gcols[g][t]` [C_g] int64 from ColourDictionary.globals_of): the result is the batch-level colour refinement itself (same
+        partition as GraphPlan.quotient finds), at the price of one `unique` + one argsort over the graphs' colours per half round
+        (not over the nodes), two sorts for the segment tables and one sort of the nodes for the last stage's sums."""
+        N, dev = self.N, self.device
+        i64 = dict(dtype=torch.int64, device=dev)
+        counts = sorted({int(c) for c in (max_stages if isinstance(max_stages, (tuple, list, set)) else [max_stages]) if int(c) > 0})
+        S = min([len(p) for p in parts] + [max(counts + [0])])
+        G = len(parts)
+        stages = []
+        if N >= self.QUOTIENT_MIN_NODES and self.E > 0:
+            n_nodes = [int(node_off[g + 1]) - int(node_off[g]) for g in range(G)]
+            inv_prev, prev_off, Cp = None, [0] * G, 1
+            zero1 = torch.zeros(1, dtype=torch.int32, device=dev)
+
+            def spread(offs, lens, total):
+                return torch.repeat_interleave(torch.tensor(offs, **i64), torch.tensor(lens, **i64), output_size=total)
+            for t in range(S):
+                st = [p[t] for p in parts]
+                Cs = [s_['C'] for s_ in st]
+                Ctot = sum(Cs)
+                coff = [0] * G
+                for g in range(1, G):
+                    coff[g] = coff[g - 1] + Cs[g - 1]
+                n_ents = [int(s_['raw']['ent'].numel()) for s_ in st]
+                eoff = [0] * G
+                for g in range(1, G):
+                    eoff[g] = eoff[g - 1] + n_ents[g - 1]
+                uniq, inv = torch.unique(torch.cat([gcols[g][t] for g in range(G)]), return_inverse=True)
+                C = int(uniq.numel())
+                if C * self.QUOTIENT_FRACTION > N:
+                    break
+                # the first colour (in concatenation order) of every merged colour represents it
+                order = torch.sort(inv, stable=True).indices
+                members = torch.bincount(inv, minlength=C)
+                rep = order[torch.cumsum(members, 0) - members]
+                cid = inv[torch.cat([s_['cid'] for s_ in st]).long() + spread(coff, n_nodes, N)]
+                start_cc = torch.cat([s_['raw']['rptr'][:-1] for s_ in st]) + spread(eoff, Cs, Ctot)
+                len_cc = torch.cat([s_['raw']['rptr'][1:] - s_['raw']['rptr'][:-1] for s_ in st])
+                ent_cc = torch.cat([s_['raw']['ent'] for s_ in st])
+                own_cc = torch.cat([s_['raw']['own'] for s_ in st])
+                if t > 0:                    # previous colours: the graph's numbering -> concatenation index -> merged id of stage t-1
+                    ent_cc = inv_prev[ent_cc + spread(prev_off, n_ents, sum(n_ents))]
+                    own_cc = inv_prev[own_cc + spread(prev_off, Cs, Ctot)]
+                dr = len_cc[rep]
+                rptr = torch.zeros(C + 1, **i64)
+                rptr[1:] = torch.cumsum(dr, 0)
+                n_ent = int(rptr[-1].item())
+                row = torch.repeat_interleave(torch.arange(C, **i64), dr, output_size=n_ent)
+                ent = ent_cc[start_cc[rep][row] + (torch.arange(n_ent, **i64) - rptr[row])] if n_ent else torch.zeros(0, **i64)
+                own = own_cc[rep]
+                heavy = torch.nonzero(dr > self.HEAVY_ROW).reshape(-1).to(torch.int32)
+                own_o, own_levels = self.class_sum_levels(own, Cp)
+                ent_o, ent_levels = self.class_sum_levels(ent, Cp)
+                stages.append(dict(C=C, cid=cid.to(torch.int32).contiguous(), rev=st[0]['rev'], ptr=rptr.to(torch.int32).contiguous(),
+                                   idx=(ent + C).to(torch.int32).contiguous() if n_ent else zero1,
+                                   ent_idx=ent.to(torch.int32).contiguous() if n_ent else zero1,
+                                   own=own, own32=own.to(torch.int32).contiguous(), xcls=torch.cat([s_['xcls'] for s_ in st])[rep].contiguous(),
+                                   heavy=(int(heavy.numel()), heavy.contiguous()), own_rows=own_o, own_levels=own_levels,
+                                   ent_rows=row[ent_o.long()].to(torch.int32).contiguous() if n_ent else zero1, ent_levels=ent_levels))
+                inv_prev, prev_off, Cp = inv, coff, C
+        out = {}
+        for c in counts:
+            lst = list(stages[:c])
+            if lst:
+                last = dict(lst[-1])
+                last['sum_levels'] = self.class_sum_levels(last['cid'], last['C'])
                 lst[-1] = last
             out[c] = lst
         xc = getattr(self, 'xcls', None)

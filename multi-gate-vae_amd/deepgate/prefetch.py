@@ -127,10 +127,17 @@ class BatchPrefetcher:
 
     # ---- per-graph colour refinement, cached on the graph (a dataset's graphs come back every epoch, in other batches)
     PARTS_CACHE_BYTES = 16 << 30         # device bytes of cached per-graph stages; beyond: batches refine their colours themselves
-    # Off by default.  Measured at config 2 (round 4, tools/assemble_probe.py, bench.py): the assembly costs 6.8 ms of device time per batch
-    # against 9.6 for the batch-level refinement, but colours are not merged ACROSS graphs: 192 / 6,000 / 460,531 colours in three stages
-    # instead of 3 / 152 / 34,377 / 1,662,243 in four, so the step itself is ~3 ms slower: fresh-batch loop 76.7 ms against 73.8.
+    # How a fresh batch gets its quotient stages (the early half rounds of the structural encoder on one row per colour):
+    #   False      the batch refines its colours itself (GraphPlan.quotient: 9.6 ms of device time per config-2 batch)
+    #   'separate' from its graphs' cached stages, colours NOT merged across graphs (assemble_quotient: cheaper plan, but 192 / 6,000 /
+    #              460,531 colours in three stages instead of 3 / 152 / 34,377 / 1,662,243 in four: the step is ~3 ms slower; measured
+    #              76.7 ms per fresh-batch step against 73.8)
+    #   'merged'   from its graphs' cached stages, merged through the dataset-wide ColourDictionary: exactly the batch-level refinement
+    #              (3 / 152 / 34,377 / 1,662,243), but the merge needs a sort of the graphs' colours, two sorts for the segment tables per
+    #              stage and one of the nodes: as much device time as refining (measured 73.5 ms per fresh-batch step against 73.8)
+    # Neither cached form pays at config 2: the cost of a batch's stages is building their tables, not finding the colours.  Default: False.
     PER_GRAPH_QUOTIENT = False
+    _colour_dict = None
     _parts_lock = threading.Lock()
     _parts_bytes = 0
 
@@ -145,8 +152,8 @@ class BatchPrefetcher:
             return None
         if sum(int(g['num_nodes']) for g in graphs) < GraphPlan.QUOTIENT_MIN_NODES:
             return None
-        key = (str(self.device), max_st)
-        parts = []
+        key = (str(self.device), max_st, self.PER_GRAPH_QUOTIENT)
+        parts, gcols = [], []
         for g in graphs:
             hit = g.get('_mgv_quot', {}).get(key) if isinstance(g.get('_mgv_quot'), dict) else None
             if hit is None:
@@ -160,6 +167,16 @@ class BatchPrefetcher:
                         xc = torch.from_numpy(np.ascontiguousarray(np.asarray(g['x'])[:, 1]).astype(np.uint8)).to(self.device, non_blocking=True)
                         st = GraphPlan(ei, n).quotient(xc, max_st, force=True)
                         st = [dict(C=s_['C'], cid=s_['cid'], rev=s_['rev'], xcls=s_['xcls'], raw=s_['raw']) for s_ in st]
+                        gcol = None
+                        if self.PER_GRAPH_QUOTIENT == 'merged':
+                            # global ids of the graph's colours: the representatives' signatures through the dataset-wide dictionary
+                            # (host side, once per graph: the only read-back of this path)
+                            if BatchPrefetcher._colour_dict is None:
+                                from .graph_plan import ColourDictionary
+                                BatchPrefetcher._colour_dict = ColourDictionary()
+                            host = [dict(ptr=s_['raw']['rptr'].cpu().numpy(), ent=s_['raw']['ent'].cpu().numpy(),
+                                         own=s_['raw']['own'].cpu().numpy(), xcls=s_['xcls'].cpu().numpy()) for s_ in st]
+                            gcol = [torch.from_numpy(v).to(self.device, non_blocking=True) for v in BatchPrefetcher._colour_dict.globals_of(host)]
                         ev = torch.cuda.Event()
                         ev.record(stream)
                         nbytes = 0
@@ -169,11 +186,12 @@ class BatchPrefetcher:
                                     if torch.is_tensor(t):
                                         nbytes += t.numel() * t.element_size()
                         BatchPrefetcher._parts_bytes += nbytes
-                        hit = (st, ev)
+                        hit = (st, ev, gcol)
                         g.setdefault('_mgv_quot', {})[key] = hit
             stream.wait_event(hit[1])        # (computed on another worker's stream, possibly)
             parts.append(hit[0])
-        return parts
+            gcols.append(hit[2])
+        return parts, (gcols if self.PER_GRAPH_QUOTIENT == 'merged' and all(c is not None for c in gcols) else None)
 
     def _take_staging(self):
         st = self._free.get()
@@ -205,10 +223,13 @@ class BatchPrefetcher:
             self._free.put(st)
             if self.gate_ids is not None:
                 plan = plan_of(b, self.gate_ids)        # its few host read-backs wait on THIS stream only
-                parts = self._graph_parts(graphs, stream)
-                if parts is not None:
-                    # the batch's quotient stages from its graphs' cached ones: index arithmetic instead of a colour refinement per batch
-                    plan.assemble_quotient(parts, host['graph_ptr'].tolist(), self.quotient_stages)
+                got = self._graph_parts(graphs, stream)
+                if got is not None:
+                    # the batch's quotient stages from its graphs' cached ones instead of a colour refinement per batch
+                    if got[1] is not None:
+                        plan.assemble_quotient_merged(got[0], got[1], host['graph_ptr'].tolist(), self.quotient_stages)
+                    else:
+                        plan.assemble_quotient(got[0], host['graph_ptr'].tolist(), self.quotient_stages)
                 plan.warm(plan.xcls, self.quotient_stages)     # ... and those of the caches the step would build lazily
                 if getattr(b, 'tt_pair_index', None) is not None and b.tt_pair_index.shape[1] >= 2:
                     from . import ops

@@ -123,7 +123,8 @@ def test_npz_dataset_through_train_entry_and_first_batch_against_the_oracle(tmp_
         assert abs(a - b) <= 1e-4 * max(1.0, abs(b)), (k, a, b)
 
 
-def test_prefetched_batches_assemble_their_quotient_stages_from_per_graph_caches():
+@pytest.mark.parametrize('mode', ['merged', 'separate'])
+def test_prefetched_batches_assemble_their_quotient_stages_from_per_graph_caches(mode):
     """deepgate/prefetch.py: a fresh batch's quotient stages (the early half rounds of the structural encoder on one row per colour)
     are put together from its graphs' own cached stages (GraphPlan.assemble_quotient) instead of a colour refinement per batch.
     Two batches over the same graphs in another order: the cache is filled by the first, the stages engage in both, and a train
@@ -146,13 +147,17 @@ def test_prefetched_batches_assemble_their_quotient_stages_from_per_graph_caches
     gate_ids = [g for _, g in model.GATES]
     chunks = [graphs, graphs[2:] + graphs[:2]]
     pf = BatchPrefetcher(iter(chunks), dev, gate_ids=gate_ids, workers=2, quotient_stages=4)
-    pf.PER_GRAPH_QUOTIENT = True            # (off by default: measured slower at config 2, see deepgate/prefetch.py)
+    pf.PER_GRAPH_QUOTIENT = mode
     batches = list(pf)
     pf.close()
     assert all('_mgv_quot' in g for g in graphs)
     for b in batches:
         q = b._mgv_plan.quotient(b._mgv_plan.xcls, 4)
         assert len(q) >= 2 and 'sum_levels' in q[-1], len(q)
+        if mode == 'merged':                # the batch-level colour refinement itself: same colour counts as a plan that refines alone
+            from deepgate.graph_plan import GraphPlan
+            alone = GraphPlan(b.edge_index, b.x.shape[0]).quotient(b._mgv_plan.xcls, 4)
+            assert [s_['C'] for s_ in q] == [s_['C'] for s_ in alone[:len(q)]]
 
     def grads(batch):
         tr.optimizer.zero_grad()

@@ -492,3 +492,66 @@ def test_batch_quotient_assembled_from_per_graph_stages():
         cidl = lst[-1]['cid']
         assert sorted(order.tolist()) == list(range(N)) and bool((cidl[order.long()][1:] >= cidl[order.long()][:-1]).all())
         assert _run_seg_tables(levels, [1] * N)[:lst[-1]['C']] == torch.bincount(cidl.long(), minlength=lst[-1]['C']).tolist()
+
+
+def test_batch_quotient_merged_through_the_dataset_wide_colour_dictionary():
+    """GraphPlan.assemble_quotient_merged + ColourDictionary: the graphs' own colours merged by their dataset-wide global ids give
+    exactly the batch-level colour refinement (the partition brute force finds on the whole batch, colours shared ACROSS graphs —
+    a copy of a graph adds no colour), the representatives' lists name merged previous colours, the segment tables add up."""
+    from deepgate.graph_plan import ColourDictionary
+    graphs = [syn.make_graph('xmg', 120 + 25 * 30, 30, 70 + i, n_inputs=120) for i in range(3)]
+    graphs.append(syn.make_graph('xmg', 120 + 25 * 30, 30, 70, n_inputs=120))          # a copy of graph 0
+    a = syn.collate(graphs)
+    N, ei = a['num_nodes'], a['edge_index']
+    node_off = a['graph_ptr'].tolist()
+    old = GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES
+    GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES = 1.3, 1
+    try:
+        cd = ColourDictionary()
+        parts, gcols = [], []
+        for g in graphs:
+            xc = torch.from_numpy(g['x'][:, 1].astype('uint8'))
+            st = GraphPlan(torch.from_numpy(g['edge_index']), g['num_nodes']).quotient(xc, 3, force=True)
+            parts.append(st)
+            host = [dict(ptr=s_['raw']['rptr'].numpy(), ent=s_['raw']['ent'].numpy(), own=s_['raw']['own'].numpy(), xcls=s_['xcls'].numpy()) for s_ in st]
+            gcols.append([torch.from_numpy(v) for v in cd.globals_of(host)])
+        assert all(torch.equal(x, y) for x, y in zip(gcols[0], gcols[3]))               # the copy: the same global colours
+        plan = GraphPlan(torch.from_numpy(ei), N)
+        plan.xcls = torch.from_numpy(a['x'][:, 1].astype('uint8'))
+        out = plan.assemble_quotient_merged(parts, gcols, node_off, [2, 3])
+        assert plan.quotient(plan.xcls, 3) is out[3]
+        ref = GraphPlan(torch.from_numpy(ei), N).quotient(plan.xcls, 3)                # the batch-level refinement
+    finally:
+        GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES = old
+    q = out[3]
+    assert len(q) >= 2 and len(q) == len(ref) and [s['C'] for s in q] == [s['C'] for s in ref]
+    xcls = plan.xcls
+    col = [0] * N
+    for t, s in enumerate(q, start=1):
+        src, dst = (ei[1], ei[0]) if t % 2 == 0 else (ei[0], ei[1])
+        nb = [[] for _ in range(N)]
+        for u, v in zip(src.tolist(), dst.tolist()):
+            nb[v].append(col[u])
+        keys = [(int(xcls[i]), col[i], tuple(sorted(nb[i]))) for i in range(N)]        # no graph id: colours are shared
+        ids = {}
+        for kk in keys:
+            ids.setdefault(kk, len(ids))
+        cid = s['cid'].tolist()
+        assert len(set(zip((ids[kk] for kk in keys), cid))) == len(ids) == s['C'], t
+        assert len(set(zip(cid, ref[t - 1]['cid'].tolist()))) == s['C']                 # the same partition as GraphPlan.quotient
+        prev_cid = q[t - 2]['cid'].tolist() if t > 1 else [0] * N
+        Cp = q[t - 2]['C'] if t > 1 else 1
+        ptr, ent, own, xc = s['ptr'].tolist(), s['ent_idx'].tolist(), s['own'].tolist(), s['xcls'].tolist()
+        first = {}
+        for i, c in enumerate(cid):
+            first.setdefault(c, i)
+        for c in range(s['C']):
+            r = first[c]
+            assert xc[c] == int(xcls[r]) and own[c] == prev_cid[r]
+            assert sorted(ent[ptr[c]:ptr[c + 1]]) == sorted(prev_cid[u] for u, v in zip(src.tolist(), dst.tolist()) if v == r), (t, c)
+        assert _run_seg_tables(s['own_levels'], [1] * s['C'])[:Cp] == np.bincount(np.asarray(own), minlength=Cp).tolist()
+        if ptr[-1]:
+            assert _run_seg_tables(s['ent_levels'], [1] * ptr[-1])[:Cp] == np.bincount(np.asarray(ent[:ptr[-1]]), minlength=Cp).tolist()
+        col = [ids[kk] for kk in keys]
+    order, levels = q[-1]['sum_levels']
+    assert _run_seg_tables(levels, [1] * N)[:q[-1]['C']] == torch.bincount(q[-1]['cid'].long(), minlength=q[-1]['C']).tolist()

@@ -23,7 +23,11 @@ torch.cuda.synchronize()
 print('per-graph stages of %d graphs: %.1f ms (once per graph); stages per graph: %s; colours of graph 0: %s' % (
     len(graphs), (time.perf_counter() - t0) * 1e3, sorted({len(p) for p in parts}), [s['C'] for s in parts[0]]))
 node_off = arrays['graph_ptr'].tolist()
-for name, fn in (('assemble_quotient', lambda p: p.assemble_quotient(parts, node_off, 8)), ('quotient (batch-level refinement)', lambda p: p.quotient(xcls, 8))):
+cd = __import__("deepgate.graph_plan", fromlist=["x"]).ColourDictionary()
+t0 = time.perf_counter()
+gcols = [[torch.from_numpy(v).to(dev) for v in cd.globals_of([dict(ptr=s["raw"]["rptr"].cpu().numpy(), ent=s["raw"]["ent"].cpu().numpy(), own=s["raw"]["own"].cpu().numpy(), xcls=s["xcls"].cpu().numpy()) for s in p])] for p in parts]
+print("global colour ids through the dictionary: %.1f ms for %d graphs (once per graph); dictionary sizes %s" % ((time.perf_counter() - t0) * 1e3, len(parts), [len(m) for m in cd.maps]))
+for name, fn in (("assemble_quotient_merged", lambda p: p.assemble_quotient_merged(parts, gcols, node_off, 8)), ("assemble_quotient", lambda p: p.assemble_quotient(parts, node_off, 8)), ('quotient (batch-level refinement)', lambda p: p.quotient(xcls, 8))):
     for rep in range(2):
         p = GraphPlan(batch.edge_index, batch.x.shape[0]); p.xcls = xcls
         torch.cuda.synchronize()
