@@ -22,6 +22,11 @@
 #ifndef MGV_BWD2_D
 #define MGV_BWD2_D 3            // neighbour slots per row and gather round (2 x 3 x 2 row loads in flight per lane; 2: 1-2 % slower, same box)
 #endif
+#ifndef MGV_WG1
+#define MGV_WG1 0           // experiment (round 4): weight gradients on ONE bf16 product per term (hi x hi) instead of the three of bf16x3:
+                            // -6.7 % per launch, but 2.5e-3 of the gradient scale (a sum of N noise-like terms keeps the 2^-8 relative error
+                            // of its products: it does not average out) against the 1e-3 gradient bar: not usable; builds with it are refused
+#endif
 #ifndef MGV_ABL
 #define MGV_ABL 0            // timing ablations of diagnostic builds (results are wrong): 1 no MFMA, 2 light VALU in P2/P3, 4 no row gathers, 8 no output stores, 16 dgrad weights loaded once, 32 (with 1) no LDS fragment reads
 #endif
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                 const int k0 = 32 * half;
                 bf16x8 bh[2], bl[2];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr2(x_hi, LDP, k0, (jt0 + j) * 16); bl[j] = ldfrag_tr2(x_lo, LDP, k0, (jt0 + j) * 16); }
+                for (int j = 0; j < 2; ++j) { bh[j] = ldfrag_tr2(x_hi, LDP, k0, (jt0 + j) * 16); if (!MGV_WG1) bl[j] = ldfrag_tr2(x_lo, LDP, k0, (jt0 + j) * 16); }
 #pragma unroll
                 for (int g = 0; g < 3; ++g) {
                     const int p = g == 2 ? 2 + m : g;
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(kThreadsX3) void k_struct_stage_bwd2_x3(B2Args args
                     for (int i = 0; i < 2; ++i) {
                         const bf16x8 ah = ldfrag_tr2(ph, LDP, k0, (it0 + i) * 16), al = ldfrag_tr2(ph + PE, LDP, k0, (it0 + i) * 16);
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) mma_x3(gW[g][i * 2 + j], ah, al, bh[j], bl[j]);
+                        for (int j = 0; j < 2; ++j) { if (MGV_WG1) gW[g][i * 2 + j] = mfma_bf16(ah, bh[j], gW[g][i * 2 + j]); else mma_x3(gW[g][i * 2 + j], ah, al, bh[j], bl[j]); }
                         if (i == ig && (g == 2 || g == m)) mma_x3(gX[g == 2 ? 1 : 0], ah, al, ldfrag_tr2(xe_hi, XLD, k0, 0), ldfrag_tr2(xe_lo, XLD, k0, 0));
                     }
                 }
@@ -697,7 +702,7 @@ extern "C" int mgv_struct_stage_bwd2_x3(int H, int64_t N, const float* h_in, con
     return mgv::launch_bwd2_x3(a, workspace, workspace_floats, static_cast<hipStream_t>(stream));
 }
 
-#if MGV_ABL != 0
+#if MGV_ABL != 0 || MGV_WG1 != 0
 // marker of a timing-ablation build (wrong results by design): deepgate/_hip.py refuses a library that exports it
 extern "C" int mgv_diag_ablation_build(void) { return MGV_ABL; }
 #endif
