@@ -151,7 +151,15 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
     STAMP(1);
     const float4 us = ld4(sv.u + 4 * lr), uf = ld4(sv.u + H + 4 * lr);
     // ---- 0/1. pull dL/dhf and dL/dhs of the tile's nodes from their consumers, recompute their attention
+#ifndef MGV_LVL_EARLY_Z
+#define MGV_LVL_EARLY_Z 1
+#endif
+#ifndef MGV_LVL_EARLY_GHS
+#define MGV_LVL_EARLY_GHS 1     // dL/dhs rows leave in the pull phase (8 registers less across the MFMA phases: 22 -> 10 spilled, backward sweep 7.24 -> 6.78 ms)
+#endif
+#if !MGV_LVL_EARLY_GHS
     float4 gs_keep[2] = {zero4(), zero4()};      // dL/dhs rows, stored at the end
+#endif
     static_assert(RPG <= 2, "two kept rows");
 #pragma unroll 1
     for (int i = 0; i < RPG; ++i) {
@@ -190,11 +198,21 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
         }
         float4 dh = zero4();
         if (node >= 0) dh = add4(gf, f4(own));
+#if MGV_LVL_EARLY_GHS
+        if (row < count) st4(a.ghs + (int64_t)node * H + 4 * lr, gs);
+#else
         if (i == 0) gs_keep[0] = gs; else gs_keep[1] = gs;
+#endif
         float m, inv;
         float4 zs, zf;
         attn_reduce<H>(a, L, sp, us, uf, lr, m, inv, zs, zf);
         store_zbar<H>(z_hi, z_lo, row, lr, zs, zf);
+#if MGV_LVL_EARLY_Z
+        if (row < count) {               // the zbar row for the deferred weight gradient leaves here, in fp32 as formed (not re-read from the planes)
+            st4(a.zrows + (int64_t)(start + row) * 2 * H + 4 * lr, zs);
+            st4(a.zrows + (int64_t)(start + row) * 2 * H + H + 4 * lr, zf);
+        }
+#endif
         st4(s_dh + row * LDO + 4 * lr, dh);
         if (lr == 0) { sv.sa[row] = sp.y > sp.x ? 1.0f : 0.0f; sv.m[row] = m; sv.inv[row] = inv; }
     }
@@ -294,58 +312,11 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
             }
         STAMP(7);
     }
-    // ---- 5. d(zbar) tile to LDS (fp32, row layout for the attention backward); it overlays the dG planes
-    lds_barrier();
-#pragma unroll
-    for (int i = 0; i < S2::RTW; ++i) {
-        const int col = wc2 * 16 + r;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) s_dz[((wr2 * S2::RTW + i) * 16 + q * 4 + e) * LDZF + col] = dz[i][e];
-    }
-    lds_barrier();
-    STAMP(9);
-    // ---- 6. attention backward per in-edge: leave alpha, d(score) for the sources' pulls, d(zbar) per node.
-    // A row's stores are issued after the next row's loads.
-    float4 gus = zero4(), guf = zero4();
-    {
-        InRows<H> L[RPG];
-        int4 sp[RPG];
-        float al[RPG][kInRegs], ds[RPG][kInRegs];
-        sp[0] = ix.span[grp];
-        L[0].issue(a, ix.insrc + grp * kInCap, sp[0].y - sp[0].x, lr);
-#pragma unroll
-        for (int i = 0; i < RPG; ++i) {
-            const int row = grp + i * GROUPS;
-            const float4 dzs = ld4(s_dz + row * LDZF + 4 * lr), dzf = ld4(s_dz + row * LDZF + H + 4 * lr);
-            const bf16x4 zsh = *reinterpret_cast<const bf16x4*>(z_hi + row * LDZP + 4 * lr), zsl = *reinterpret_cast<const bf16x4*>(z_lo + row * LDZP + 4 * lr);
-            const bf16x4 zfh = *reinterpret_cast<const bf16x4*>(z_hi + row * LDZP + H + 4 * lr), zfl = *reinterpret_cast<const bf16x4*>(z_lo + row * LDZP + H + 4 * lr);
-            const float4 zs = make_float4((float)zsh[0] + (float)zsl[0], (float)zsh[1] + (float)zsl[1], (float)zsh[2] + (float)zsl[2], (float)zsh[3] + (float)zsl[3]);
-            const float4 zf = make_float4((float)zfh[0] + (float)zfl[0], (float)zfh[1] + (float)zfl[1], (float)zfh[2] + (float)zfl[2], (float)zfh[3] + (float)zfl[3]);
-            if (row < count) attn_bwd_row<H>(a, L[i], sp[i], us, uf, dzs, dzf, sv.m[row], sv.inv[row], lr, al[i], ds[i], gus, guf);
-            if (i == 0) { STAMP(12); } else { STAMP(14); }
-            if (i + 1 < RPG) {
-                sp[i + 1] = ix.span[row + GROUPS];
-                L[i + 1].issue(a, ix.insrc + (row + GROUPS) * kInCap, sp[i + 1].y - sp[i + 1].x, lr);
-            }
-            if (row < count) {
-                const int64_t node = ix.node[row];
-                const int64_t pos = start + row;
-                st4(a.dzb + node * 2 * H + 4 * lr, dzs);
-                st4(a.dzb + node * 2 * H + H + 4 * lr, dzf);
-                st4(a.zrows + pos * 2 * H + 4 * lr, zs);
-                st4(a.zrows + pos * 2 * H + H + 4 * lr, zf);
-                st4(a.ghs + node * H + 4 * lr, gs_keep[i]);
-                const int deg = sp[i].y - sp[i].x;
-                if (lr == 0) {
-#pragma unroll
-                    for (int k = 0; k < kInRegs; ++k)
-                        if (k < deg) { a.alpha[sp[i].x + k] = al[i][k]; a.dsc[sp[i].x + k] = ds[i][k]; }
-                }
-            }
-            if (i == 0) { STAMP(13); }
-        }
-    }
-    STAMP(10);
+#ifndef MGV_LVL_EARLY_DG
+#define MGV_LVL_EARLY_DG 1        // with the early dL/dhs store and the re-read attention vector: 22 -> 2 spilled registers, backward sweep 7.4 -> 6.85 ms
+#endif
+#if MGV_LVL_EARLY_DG
+    // (behind the passes, not at the end of the tile: the 24 gate-gradient registers are free during the attention backward)
     // gate gradients of the tile's rows, for the weight-gradient kernel
     {
         const int col = wc * 16 + r;
@@ -360,6 +331,85 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
                 }
             }
     }
+#endif
+    // ---- 5. d(zbar) tile to LDS (fp32, row layout for the attention backward); it overlays the dG planes
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < S2::RTW; ++i) {
+        const int col = wc2 * 16 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_dz[((wr2 * S2::RTW + i) * 16 + q * 4 + e) * LDZF + col] = dz[i][e];
+    }
+    lds_barrier();
+    STAMP(9);
+    // ---- 6. attention backward per in-edge: leave alpha, d(score) for the sources' pulls, d(zbar) per node.
+    // A row's stores are issued after the next row's loads.
+    float4 gus = zero4(), guf = zero4();
+    {
+        // (the attention vector re-read from LDS: 8 registers not carried across the MFMA phases)
+        int lr6 = lr;
+        asm volatile("" : "+v"(lr6));
+        const float4 us6 = ld4(sv.u + 4 * lr6), uf6 = ld4(sv.u + H + 4 * lr6);
+        InRows<H> L[RPG];
+        int4 sp[RPG];
+        float al[RPG][kInRegs], ds[RPG][kInRegs];
+        sp[0] = ix.span[grp];
+        L[0].issue(a, ix.insrc + grp * kInCap, sp[0].y - sp[0].x, lr);
+#pragma unroll
+        for (int i = 0; i < RPG; ++i) {
+            const int row = grp + i * GROUPS;
+            const float4 dzs = ld4(s_dz + row * LDZF + 4 * lr), dzf = ld4(s_dz + row * LDZF + H + 4 * lr);
+#if !MGV_LVL_EARLY_Z
+            const bf16x4 zsh = *reinterpret_cast<const bf16x4*>(z_hi + row * LDZP + 4 * lr), zsl = *reinterpret_cast<const bf16x4*>(z_lo + row * LDZP + 4 * lr);
+            const bf16x4 zfh = *reinterpret_cast<const bf16x4*>(z_hi + row * LDZP + H + 4 * lr), zfl = *reinterpret_cast<const bf16x4*>(z_lo + row * LDZP + H + 4 * lr);
+            const float4 zs = make_float4((float)zsh[0] + (float)zsl[0], (float)zsh[1] + (float)zsl[1], (float)zsh[2] + (float)zsl[2], (float)zsh[3] + (float)zsl[3]);
+            const float4 zf = make_float4((float)zfh[0] + (float)zfl[0], (float)zfh[1] + (float)zfl[1], (float)zfh[2] + (float)zfl[2], (float)zfh[3] + (float)zfl[3]);
+#endif
+            if (row < count) attn_bwd_row<H>(a, L[i], sp[i], us6, uf6, dzs, dzf, sv.m[row], sv.inv[row], lr, al[i], ds[i], gus, guf);
+            if (i == 0) { STAMP(12); } else { STAMP(14); }
+            if (i + 1 < RPG) {
+                sp[i + 1] = ix.span[row + GROUPS];
+                L[i + 1].issue(a, ix.insrc + (row + GROUPS) * kInCap, sp[i + 1].y - sp[i + 1].x, lr);
+            }
+            if (row < count) {
+                const int64_t node = ix.node[row];
+                const int64_t pos = start + row;
+                st4(a.dzb + node * 2 * H + 4 * lr, dzs);
+                st4(a.dzb + node * 2 * H + H + 4 * lr, dzf);
+#if !MGV_LVL_EARLY_Z
+                st4(a.zrows + pos * 2 * H + 4 * lr, zs);
+                st4(a.zrows + pos * 2 * H + H + 4 * lr, zf);
+#endif
+#if !MGV_LVL_EARLY_GHS
+                st4(a.ghs + node * H + 4 * lr, gs_keep[i]);
+#endif
+                const int deg = sp[i].y - sp[i].x;
+                if (lr == 0) {
+#pragma unroll
+                    for (int k = 0; k < kInRegs; ++k)
+                        if (k < deg) { a.alpha[sp[i].x + k] = al[i][k]; a.dsc[sp[i].x + k] = ds[i][k]; }
+                }
+            }
+            if (i == 0) { STAMP(13); }
+        }
+    }
+    STAMP(10);
+#if !MGV_LVL_EARLY_DG
+    // gate gradients of the tile's rows, for the weight-gradient kernel
+    {
+        const int col = wc * 16 + r;
+#pragma unroll
+        for (int i = 0; i < S::RTW; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = (wr * S::RTW + i) * 16 + q * 4 + e;
+                if (row < count) {
+                    float* dg = a.dgrows + (int64_t)(start + row) * 3 * H + col;
+                    dg[0] = ar[i][e]; dg[H] = az[i][e]; dg[2 * H] = an[i][e];
+                }
+            }
+    }
+#endif
     // d(attention vector): the lane groups of a wave that share a column quad meet by shuffles (fixed tree), the eight waves through
     // an LDS stage over the (now dead) zbar planes, summed in wave order — no LDS float atomics, bit-reproducible
     {
