@@ -167,7 +167,9 @@ def roofline_record(summ, table, N, E, H, step_s):
     f_step = 3.0 * (993472.0 * N + 33280.0 * E + 49152.0 * n_g)
     roof['step'] = {'bytes_8d': b_step, 'hbm_frac': b_step / step_s / 1e9 / PEAK_HBM_GBPS, 'flops_8d': f_step,
                     'mfma_frac_bf16x3': 3 * f_step / step_s / 1e12 / PEAK_BF16_MFMA_TFLOPS}
-    for names, key in ((('r03_pmc_traffic.json', 'r02_pmc_traffic.json'), 'traffic'), (('r03_pmc_mfma.json', 'r02_pmc_mfma.json'), 'mfma')):
+    import glob
+    for suffix, key in (('_pmc_traffic.json', 'traffic'), ('_pmc_mfma.json', 'mfma')):
+        names = sorted((os.path.basename(f) for f in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]' + suffix))), reverse=True)
         pmc, fname = None, None
         for fname in names:              # the newest committed counter pass
             try:

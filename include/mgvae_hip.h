@@ -212,8 +212,9 @@ int mgv_func_sweep_round_bwd(int H, int64_t N, int T, int num_levels, const int3
 /* the sweep on bf16x3 split-precision MFMA (H in {32, 64}, T <= 6).  Differences from the fp32 entry points:
  * wpack_bf16[T][4][6H^2] = per slot {Wvc_hi, Wvc_lo, WvcT_hi, WvcT_lo} as bf16 in MFMA fragment order
  * (blocks (row tile, k-step) of 512 elements, lane 16q+r holds W[16 rt + r][32 ks + 8q .. +7]);
- * order_span[n_active][4] = {in_ptr[v], in_ptr[v+1], out_ptr[v], out_ptr[v+1]} of v = order[i] (the CSR
- * spans in sweep order, so a tile reaches its edge lists with one load per row).
+ * order_span[n_active][order_span_ints]: order_span_ints = 4: {in_ptr[v], in_ptr[v+1], out_ptr[v], out_ptr[v+1]} of v = order[i] (the CSR
+ * spans in sweep order, so a tile reaches its edge lists with one load per row); order_span_ints = 32: the packed rows of
+ * mgv_plan_order_rows (spans + the first in-edge sources and consumers: the lists themselves arrive with that one load).
  * Backward: no float atomics per tile.  The level kernels leave their rows' gate gradients and zbar rows in
  * `scratch` (sweep order) and one weight-gradient kernel per slot forms dWvc afterwards from the slot's tile
  * list: slot_tiles[num_tiles] = tile ids grouped by slot, slot_tile_ptr_host = HOST array [T+1] of offsets into
@@ -225,12 +226,12 @@ int mgv_func_sweep_round_bwd(int H, int64_t N, int T, int num_levels, const int3
  * with it the caller hands the sweep an UNINITIALISED hf instead of a zero-filled one */
 int mgv_sweep_zero_inactive(int H, int64_t N, const uint8_t* gslot, float* hf, void* stream);
 int mgv_func_sweep_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                          const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
+                          const int32_t* order, const int32_t* order_span, int order_span_ints, const int32_t* tile_start,
                           const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
                           const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
                           const void* wpack_bf16, const float* bvc, const float* bih, const float* bhh, void* stream);
 int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                          const int32_t* order, const int32_t* order_span, int64_t n_active,
+                          const int32_t* order, const int32_t* order_span, int order_span_ints, int64_t n_active,
                           const int32_t* tile_start, const int32_t* tile_count, const int32_t* tile_slot,
                           const int32_t* slot_tiles, const int32_t* slot_tile_ptr_host, const int32_t* in_ptr,
                           const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
@@ -256,13 +257,13 @@ int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t
  * backward: d_gh[N][3H] (rows of updated nodes written) and g_hprev[N][H] = dh * z (the caller zeroes it: other rows are not written);
  * the dbhh accumulator receives nothing meaningful (its gradient comes from the caller's linear kernels). */
 int mgv_func_sweep_round_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                          const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
+                          const int32_t* order, const int32_t* order_span, int order_span_ints, const int32_t* tile_start,
                           const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
                           const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
                           const void* wpack_bf16, const float* bvc, const float* bih, const float* zero_bhh,
                           const float* gh, const float* h_prev, void* stream);
 int mgv_func_sweep_round_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                          const int32_t* order, const int32_t* order_span, int64_t n_active,
+                          const int32_t* order, const int32_t* order_span, int order_span_ints, int64_t n_active,
                           const int32_t* tile_start, const int32_t* tile_count, const int32_t* tile_slot,
                           const int32_t* slot_tiles, const int32_t* slot_tile_ptr_host, const int32_t* in_ptr,
                           const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
@@ -474,6 +475,10 @@ int mgv_plan_tile_counts(int K, const int32_t* key_start, int32_t* ntile, int32_
 int mgv_plan_tiles(int K, int T, int L, int64_t n_active, const int32_t* key_start, const int32_t* tile_first, const int32_t* order,
                    const int32_t* in_ptr, const int32_t* out_ptr, int32_t* tile_start, int32_t* tile_count, int32_t* tile_slot,
                    int32_t* order_span, int32_t* level_tile_ptr, void* stream);
+/* packed sweep rows, 32 ints per updated node in sweep order: spans, first 4 in-edge sources, first 8 consumers (node, in-CSR slot) and
+ * their gate slots (plan_build.hip k_order_rows); handed to the level sweeps as order_span with order_span_ints = 32 */
+int mgv_plan_order_rows(int64_t n_active, const int32_t* order, const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                        const int32_t* out_dst, const int32_t* out_slot, const uint8_t* gslot, int32_t* rows, void* stream);
 int mgv_plan_pairs(int64_t N, const int32_t* in_ptr, const uint8_t* xcls, int32_t* present, int32_t* rank, int32_t* scan_scratch, int32_t* cid,
                    int32_t* cls_deg, uint8_t* cls_x, int32_t* status, void* stream);
 

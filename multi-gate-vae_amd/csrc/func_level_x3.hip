@@ -35,8 +35,10 @@ __global__ __launch_bounds__(kLT, 4) void k_level_fwd_x3(LevelX3Args a) {
     const int grp = tid / LPR, lr = tid % LPR;
     lds_barrier();
     STAMP(0);
-    stage_in_edges(a, ix);
-    lds_barrier();
+    if (a.span_ints != kRowInts) {       // (packed rows brought the in-edge sources with the spans)
+        stage_in_edges(a, ix);
+        lds_barrier();
+    }
     STAMP(1);
     const float4 us = ld4(sv.u + 4 * lr), uf = ld4(sv.u + H + 4 * lr);
     {
@@ -143,10 +145,16 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
     // the end — same result whichever wave adds first
     float* slab_small = a.wslab + ((int64_t)blockIdx.x * a.T + g) * (11 * H);
     for (int i = tid; i < 11 * H; i += kLT) s_gu[i] = 0.f;
-    lds_barrier();
-    STAMP(0);
-    stage_in_edges(a, ix);
-    stage_out_edges(a, ix, os);
+    const bool packed = a.span_ints == kRowInts;
+    const int out_cap = packed ? kRowOut : kOutCap;          // consumers per row staged in LDS (the rest: pull_tail)
+    if (packed) {
+        stage_out_edges_packed(a, start, count, os);         // spans, in-edge sources, consumers and their scalars: one staging phase
+    } else {
+        lds_barrier();
+        STAMP(0);
+        stage_in_edges(a, ix);
+        stage_out_edges(a, ix, os);
+    }
     lds_barrier();
     STAMP(1);
     const float4 us = ld4(sv.u + 4 * lr), uf = ld4(sv.u + H + 4 * lr);
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
                 if (v < node) lo = mid + 1; else hi = mid - 1;
             }
         }
-        const int nout = hk >= 0 ? 0 : min(sp.w - sp.z, kOutCap);
+        const int nout = hk >= 0 ? 0 : min(sp.w - sp.z, out_cap);
         InRows<H> L;
         OutRows<H> P;
         f32x4 own;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(kLT, 4) void k_level_bwd_x3(LevelX3Args a) {
             gs = ld4(a.heavy_pull + (int64_t)hk * 2 * H + 4 * lr);
             gf = ld4(a.heavy_pull + (int64_t)hk * 2 * H + H + 4 * lr);
         } else {
-            pull_tail<H>(a, sp.z + kOutCap, sp.w, lr, gs, gf);
+            pull_tail<H>(a, sp.z + out_cap, sp.w, lr, gs, gf);
         }
         float4 dh = zero4();
         if (node >= 0) dh = add4(gf, f4(own));
@@ -650,15 +658,16 @@ extern "C" int mgv_sweep_zero_inactive(int H, int64_t N, const uint8_t* gslot, f
 }
 
 static int sweep_fwd_x3_impl(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                             const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
+                             const int32_t* order, const int32_t* order_span, int order_span_ints, const int32_t* tile_start,
                              const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
                              const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
                              const void* wpack_bf16, const float* bvc, const float* bih, const float* bhh,
                              const float* gh, const float* h_prev, void* stream) {
     MGV_CHECK_ARG(N >= 0 && T >= 1 && T <= mgv::kMaxSlots && num_levels >= 0 && level_tile_ptr_host && hs && hf && attn_u && wpack_bf16 && bvc && bih && bhh && in_ptr);
+    MGV_CHECK_ARG(order_span_ints == 4 || order_span_ints == mgv::kRowInts);
     mgv::LevelX3Args a{};
     MGV_SET_LVL_STAMPS(a);
-    a.N = N; a.T = T; a.order = order; a.order_span = order_span; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot;
+    a.N = N; a.T = T; a.order = order; a.order_span = order_span; a.span_ints = order_span_ints; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot;
     a.in_ptr = in_ptr; a.in_src = in_src; a.hs = hs; a.hf = hf; a.attn_u = attn_u; a.wpack = static_cast<const __bf16*>(wpack_bf16);
     a.bvc = bvc; a.bih = bih; a.bhh = bhh;
     MGV_CHECK_ARG((gh == nullptr) == (h_prev == nullptr));
@@ -681,27 +690,27 @@ static int sweep_fwd_x3_impl(int H, int64_t N, int T, int num_levels, const int3
 }
 
 extern "C" int mgv_func_sweep_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                                     const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
+                                     const int32_t* order, const int32_t* order_span, int order_span_ints, const int32_t* tile_start,
                                      const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
                                      const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
                                      const void* wpack_bf16, const float* bvc, const float* bih, const float* bhh, void* stream) {
-    return sweep_fwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, tile_start, tile_count, tile_slot, in_ptr, in_src, hs, hf,
+    return sweep_fwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, order_span_ints, tile_start, tile_count, tile_slot, in_ptr, in_src, hs, hf,
                              attn_u, wpack_bf16, bvc, bih, bhh, nullptr, nullptr, stream);
 }
 
 extern "C" int mgv_func_sweep_round_fwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                                           const int32_t* order, const int32_t* order_span, const int32_t* tile_start,
+                                           const int32_t* order, const int32_t* order_span, int order_span_ints, const int32_t* tile_start,
                                            const int32_t* tile_count, const int32_t* tile_slot, const int32_t* in_ptr,
                                            const int32_t* in_src, const float* hs, float* hf, const float* attn_u,
                                            const void* wpack_bf16, const float* bvc, const float* bih, const float* zero_bhh,
                                            const float* gh, const float* h_prev, void* stream) {
     MGV_CHECK_ARG(gh && h_prev);
-    return sweep_fwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, tile_start, tile_count, tile_slot, in_ptr, in_src, hs, hf,
+    return sweep_fwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, order_span_ints, tile_start, tile_count, tile_slot, in_ptr, in_src, hs, hf,
                              attn_u, wpack_bf16, bvc, bih, zero_bhh, gh, h_prev, stream);
 }
 
 static int sweep_bwd_x3_impl(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                                     const int32_t* order, const int32_t* order_span, int64_t n_active,
+                                     const int32_t* order, const int32_t* order_span, int order_span_ints, int64_t n_active,
                                      const int32_t* tile_start, const int32_t* tile_count, const int32_t* tile_slot,
                                      const int32_t* slot_tiles, const int32_t* slot_tile_ptr_host, const int32_t* in_ptr,
                                      const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
@@ -717,10 +726,11 @@ static int sweep_bwd_x3_impl(int H, int64_t N, int T, int num_levels, const int3
     MGV_CHECK_ARG(N >= 0 && T >= 1 && T <= mgv::kMaxSlots && num_levels >= 0 && n_active >= 0 && level_tile_ptr_host && hs && hf &&
                   attn_u && wpack_bf16 && bvc && bih && bhh);
     MGV_CHECK_ARG(in_ptr && out_ptr && gslot && ghf && ghs && dzb && d_attn_u && dWvc && dbvc && dbih && dbhh);
+    MGV_CHECK_ARG(order_span_ints == 4 || order_span_ints == mgv::kRowInts);
     if (N == 0) return MGV_OK;
     mgv::LevelX3Args a{};
     MGV_SET_LVL_STAMPS(a);
-    a.N = N; a.T = T; a.order = order; a.order_span = order_span; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot;
+    a.N = N; a.T = T; a.order = order; a.order_span = order_span; a.span_ints = order_span_ints; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot;
     a.in_ptr = in_ptr; a.in_src = in_src; a.hs = hs; a.hf = const_cast<float*>(hf); a.attn_u = attn_u;
     a.wpack = static_cast<const __bf16*>(wpack_bf16); a.bvc = bvc; a.bih = bih; a.bhh = bhh;
     a.out_ptr = out_ptr; a.out_dst = out_dst; a.out_slot = out_slot; a.gslot = gslot;
@@ -793,7 +803,7 @@ static int sweep_bwd_x3_impl(int H, int64_t N, int T, int num_levels, const int3
 }
 
 extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                                     const int32_t* order, const int32_t* order_span, int64_t n_active,
+                                     const int32_t* order, const int32_t* order_span, int order_span_ints, int64_t n_active,
                                      const int32_t* tile_start, const int32_t* tile_count, const int32_t* tile_slot,
                                      const int32_t* slot_tiles, const int32_t* slot_tile_ptr_host, const int32_t* in_ptr,
                                      const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
@@ -805,14 +815,14 @@ extern "C" int mgv_func_sweep_bwd_x3(int H, int64_t N, int T, int num_levels, co
                                      const int32_t* heavy_nodes, const int32_t* heavy_node_seg_ptr, const int32_t* heavy_seg_e0,
                                      const int32_t* heavy_seg_e1, const int32_t* heavy_lvl_k_ptr_host,
                                      const int32_t* heavy_lvl_seg_ptr_host, float* heavy_ws, int skip_active_longer_than, void* stream) {
-    return sweep_bwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, n_active, tile_start, tile_count, tile_slot, slot_tiles,
+    return sweep_bwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, order_span_ints, n_active, tile_start, tile_count, tile_slot, slot_tiles,
                              slot_tile_ptr_host, in_ptr, in_src, out_ptr, out_dst, out_slot, gslot, hs, hf, attn_u, wpack_bf16, bvc, bih, bhh, ghf, ghs, dzb,
                              alpha, dsc, d_attn_u, dWvc, dbvc, dbih, dbhh, scratch, scratch_elems, skip_inactive_longer_than, heavy_active_n, heavy_nodes,
                              heavy_node_seg_ptr, heavy_seg_e0, heavy_seg_e1, heavy_lvl_k_ptr_host, heavy_lvl_seg_ptr_host, heavy_ws, skip_active_longer_than, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int mgv_func_sweep_round_bwd_x3(int H, int64_t N, int T, int num_levels, const int32_t* level_tile_ptr_host,
-                                     const int32_t* order, const int32_t* order_span, int64_t n_active,
+                                     const int32_t* order, const int32_t* order_span, int order_span_ints, int64_t n_active,
                                      const int32_t* tile_start, const int32_t* tile_count, const int32_t* tile_slot,
                                      const int32_t* slot_tiles, const int32_t* slot_tile_ptr_host, const int32_t* in_ptr,
                                      const int32_t* in_src, const int32_t* out_ptr, const int32_t* out_dst,
@@ -826,7 +836,7 @@ extern "C" int mgv_func_sweep_round_bwd_x3(int H, int64_t N, int T, int num_leve
                                      const int32_t* heavy_lvl_seg_ptr_host, float* heavy_ws, int skip_active_longer_than,
                                      const float* gh, const float* h_prev, float* d_gh, float* g_hprev, void* stream) {
     MGV_CHECK_ARG(gh && h_prev && d_gh && g_hprev);
-    return sweep_bwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, n_active, tile_start, tile_count, tile_slot, slot_tiles,
+    return sweep_bwd_x3_impl(H, N, T, num_levels, level_tile_ptr_host, order, order_span, order_span_ints, n_active, tile_start, tile_count, tile_slot, slot_tiles,
                              slot_tile_ptr_host, in_ptr, in_src, out_ptr, out_dst, out_slot, gslot, hs, hf, attn_u, wpack_bf16, bvc, bih, bhh, ghf, ghs, dzb,
                              alpha, dsc, d_attn_u, dWvc, dbvc, dbih, dbhh, scratch, scratch_elems, skip_inactive_longer_than, heavy_active_n, heavy_nodes,
                              heavy_node_seg_ptr, heavy_seg_e0, heavy_seg_e1, heavy_lvl_k_ptr_host, heavy_lvl_seg_ptr_host, heavy_ws, skip_active_longer_than, gh, h_prev, d_gh, g_hprev, stream);

@@ -18,6 +18,8 @@ constexpr int kInRegs = 3;             // ... of which this many source rows are
 constexpr int kOutCap = 16;            // out-edges per row staged in LDS
 constexpr int kOutChunk = 2;           // consumer rows in flight per lane while pulling
 constexpr int kWgradGrid = 256;         // workgroups of the deferred weight-gradient kernel (one slab row each)
+constexpr int kRowInts = 32;            // packed order rows: 128 bytes per updated node
+constexpr int kRowOut = 8;              // consumers per packed row
 constexpr int kMaxSlots = 6;           // gate types whose attention vectors are kept in LDS
 
 struct LevelX3Args {
@@ -25,6 +27,10 @@ struct LevelX3Args {
     int64_t N;
     int T;
     const int32_t* order; const int32_t* order_span; const int32_t* tile_start; const int32_t* tile_count; const int32_t* tile_slot;
+    // ints per row of order_span: 4 = {in0, in1, out0, out1}; kRowInts = packed rows (GraphPlan.order_rows): the spans, then the first
+    // 4 in-edge sources, the first kRowOut consumers as (node, in-CSR slot) pairs and their gate slots — a tile then reaches its
+    // rows' lists with ONE load level instead of span -> edge lists -> gslot
+    int span_ints;
     int tile_begin;
     const int32_t* in_ptr; const int32_t* in_src;
     const float* hs; float* hf;
@@ -118,18 +124,23 @@ __device__ __forceinline__ LvlIdx lvl_idx(unsigned char* base) {
     return x;
 }
 
-// rows' node ids and CSR spans {in0, in1, out0, out1}; padding rows get node -1 and empty spans
+// rows' node ids and CSR spans {in0, in1, out0, out1}; padding rows get node -1 and empty spans.  Packed rows: the in-edge sources too.
 __device__ __forceinline__ void stage_spans(const LevelX3Args& a, int start, int count, const LvlIdx& x) {
+    const int stride = a.span_ints;
     if (threadIdx.x < kTileRows) {
         const int row = threadIdx.x;
         int node = -1;
         int4 sp = make_int4(0, 0, 0, 0);
         if (row < count) {
             node = a.order[start + row];
-            sp = *reinterpret_cast<const int4*>(a.order_span + 4 * (int64_t)(start + row));
+            sp = *reinterpret_cast<const int4*>(a.order_span + (int64_t)stride * (start + row));
         }
         x.node[row] = node;
         x.span[row] = sp;
+    }
+    if (stride == kRowInts && threadIdx.x < kTileRows * kInCap) {
+        const int row = threadIdx.x / kInCap, k = threadIdx.x % kInCap;
+        if (row < count) x.insrc[threadIdx.x] = a.order_span[(int64_t)stride * (start + row) + 4 + k];
     }
 }
 
@@ -162,6 +173,22 @@ __device__ __forceinline__ void stage_out_edges(const LevelX3Args& a, const LvlI
             float al = 0.f, ds = 0.f;
             if (gc != kNoGateX) { al = a.alpha[sl]; ds = a.dsc[sl]; }
             o.c[i] = c; o.al[i] = al; o.ds[i] = ds; o.gc[i] = gc;
+        }
+    }
+}
+
+// the same from the packed rows: one thread per (row, consumer k < kRowOut); no dependence on the spans in LDS
+__device__ __forceinline__ void stage_out_edges_packed(const LevelX3Args& a, int start, int count, const OutStage& o) {
+    const int row = threadIdx.x / kRowOut, k = threadIdx.x % kRowOut;
+    if (row < count) {
+        const int32_t* rp = a.order_span + (int64_t)kRowInts * (start + row);
+        const int2 cs = *reinterpret_cast<const int2*>(rp + 8 + 2 * k);
+        const uint8_t gc = reinterpret_cast<const uint8_t*>(rp + 24)[k];
+        if (cs.x >= 0) {
+            float al = 0.f, ds = 0.f;
+            if (gc != kNoGateX) { al = a.alpha[cs.y]; ds = a.dsc[cs.y]; }
+            const int i = row * kOutCap + k;
+            o.c[i] = cs.x; o.al[i] = al; o.ds[i] = ds; o.gc[i] = gc;
         }
     }
 }

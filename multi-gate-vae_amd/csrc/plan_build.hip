@@ -545,6 +545,54 @@ extern "C" int mgv_plan_tiles(int K, int T, int L, int64_t n_active, const int32
     MGV_LAUNCH_RET();
 }
 
+/* Packed sweep rows (func_level_x3_common.h: kRowInts = 32 ints = one 128-byte line per updated node, in sweep order):
+ * [0..3] the CSR spans, [4..7] the first 4 in-edge sources (-1: none), [8..23] the first 8 consumers as (node, in-CSR slot) pairs (node -1: none),
+ * [24..25] their gate slots (bytes), [26..31] unused.  Eight threads per row, one 16-byte piece each. */
+__global__ void __launch_bounds__(256) k_order_rows(int64_t n_active, const int32_t* __restrict__ order, const int32_t* __restrict__ in_ptr,
+                                                    const int32_t* __restrict__ in_src, const int32_t* __restrict__ out_ptr,
+                                                    const int32_t* __restrict__ out_dst, const int32_t* __restrict__ out_slot,
+                                                    const uint8_t* __restrict__ gslot, int4* __restrict__ rows) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = t >> 3;
+    const int k = (int)(t & 7);
+    if (i >= n_active) return;
+    const int v = order[i];
+    int4 o = make_int4(-1, -1, -1, -1);
+    if (k == 0) {
+        o = make_int4(in_ptr[v], in_ptr[v + 1], out_ptr[v], out_ptr[v + 1]);
+    } else if (k == 1) {
+        const int a = in_ptr[v], b = in_ptr[v + 1];
+        if (a + 0 < b) o.x = in_src[a + 0];
+        if (a + 1 < b) o.y = in_src[a + 1];
+        if (a + 2 < b) o.z = in_src[a + 2];
+        if (a + 3 < b) o.w = in_src[a + 3];
+    } else if (k < 6) {
+        const int a = out_ptr[v] + 2 * (k - 2), b = out_ptr[v + 1];
+        if (a < b) { o.x = out_dst[a]; o.y = out_slot[a]; }
+        if (a + 1 < b) { o.z = out_dst[a + 1]; o.w = out_slot[a + 1]; }
+    } else if (k == 6) {
+        const int a = out_ptr[v], b = out_ptr[v + 1];
+        uint32_t lo = 0xffffffffu, hi = 0xffffffffu;
+        for (int j = 0; j < 8 && a + j < b; ++j) {
+            const uint32_t gc = gslot[out_dst[a + j]];
+            if (j < 4) lo = (lo & ~(0xffu << (8 * j))) | (gc << (8 * j));
+            else hi = (hi & ~(0xffu << (8 * (j - 4)))) | (gc << (8 * (j - 4)));
+        }
+        o.x = (int)lo; o.y = (int)hi;
+    }
+    rows[i * 8 + k] = o;
+}
+
+extern "C" int mgv_plan_order_rows(int64_t n_active, const int32_t* order, const int32_t* in_ptr, const int32_t* in_src, const int32_t* out_ptr,
+                                   const int32_t* out_dst, const int32_t* out_slot, const uint8_t* gslot, int32_t* rows, void* stream) {
+    MGV_CHECK_ARG(n_active >= 0);
+    if (n_active == 0) return MGV_OK;
+    MGV_CHECK_ARG(order && in_ptr && out_ptr && gslot && rows && (reinterpret_cast<uintptr_t>(rows) & 15) == 0);
+    hipLaunchKernelGGL(k_order_rows, dim3((unsigned)((n_active * 8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n_active, order,
+                       in_ptr, in_src, out_ptr, out_dst, out_slot, gslot, reinterpret_cast<int4*>(rows));
+    MGV_LAUNCH_RET();
+}
+
 /* (in-degree, feature class) pairs -> class ids: present/rank are scratch of 65,537 ints each (+ scan scratch of 64); n_cls = rank[65536]
  * (device); status[0] = 3 when a degree exceeds 255 (caller falls back to per-node launches) */
 extern "C" int mgv_plan_pairs(int64_t N, const int32_t* in_ptr, const uint8_t* xcls, int32_t* present, int32_t* rank, int32_t* scan_scratch, int32_t* cid,

@@ -802,7 +802,7 @@ extern "C" int mgv_func_sweep_fwd_persist_x3(int H, int64_t N, int T, int num_le
     mgv::PersistArgs pa{};
     mgv::LevelX3Args& a = pa.a;
     MGV_SET_PERSIST_STAMPS(a);
-    a.N = N; a.T = T; a.order = order; a.order_span = order_span; a.tile_start = tile_start; a.tile_count = tile_count;
+    a.N = N; a.T = T; a.order = order; a.order_span = order_span; a.span_ints = 4; a.tile_start = tile_start; a.tile_count = tile_count;
     a.in_ptr = in_ptr; a.in_src = in_src; a.hs = hs; a.hf = hf; a.attn_u = attn_u; a.wpack = static_cast<const __bf16*>(wpack_bf16);
     a.bvc = bvc; a.bih = bih; a.bhh = bhh;
     pa.num_levels = num_levels; pa.key_tile_ptr = key_tile_ptr;
@@ -838,7 +838,7 @@ extern "C" int mgv_func_sweep_bwd_persist_x3(int H, int64_t N, int T, int num_le
     mgv::PersistArgs pa{};
     mgv::LevelX3Args& a = pa.a;
     MGV_SET_PERSIST_STAMPS(a);
-    a.N = N; a.T = T; a.order = order; a.order_span = order_span; a.tile_start = tile_start; a.tile_count = tile_count;
+    a.N = N; a.T = T; a.order = order; a.order_span = order_span; a.span_ints = 4; a.tile_start = tile_start; a.tile_count = tile_count;
     a.in_ptr = in_ptr; a.in_src = in_src; a.hs = hs; a.hf = const_cast<float*>(hf); a.attn_u = attn_u;
     a.wpack = static_cast<const __bf16*>(wpack_bf16); a.bvc = bvc; a.bih = bih; a.bhh = bhh;
     a.out_ptr = out_ptr; a.out_dst = out_dst; a.out_slot = out_slot; a.gslot = gslot;

@@ -186,6 +186,8 @@ class GraphPlan:
             self.heavy_segments(True, inactive_only=True)
             self.heavy_segments(True, active_by_level=True)
         from . import ops
+        if self.has_levels and ops.PACKED_ROWS:
+            self.order_rows
         counts = sorted({int(c) for c in (quotient_stages if isinstance(quotient_stages, (tuple, list, set)) else [quotient_stages]) if int(c) > 0})
         if xcls is not None and self.N > 0 and counts and ops.QUOTIENT:
             if all([len(self.quotient(xcls, c)) > 0 for c in counts]):
@@ -655,6 +657,7 @@ class GraphPlan:
         self.__dict__.pop('_tagged', None)
         self.__dict__.pop('_slot_nodes', None)
         self.__dict__.pop('_persist_roles', None)
+        self.__dict__.pop('_order_rows', None)
 
     def _set_levels_hip(self, gate, forward_level, gate_ids):
         from . import _hip
@@ -713,6 +716,45 @@ class GraphPlan:
         self.num_tiles, self.n_active, self.num_slots = num_tiles, n_active, T
         self.has_levels = True
         return self
+
+    ROW_INTS = 32           # func_level_x3_common.h kRowInts
+    ROW_OUT = 8
+
+    @property
+    def order_rows(self):
+        """Packed sweep rows [n_active, 32] int32 (one 128-byte line per updated node, sweep order): {in0, in1, out0, out1}, the first 4
+        in-edge sources (-1: none), the first 8 consumers as (node, in-CSR slot) pairs (node -1: none), their gate slots as bytes.
+        The level kernels reach a tile's lists with this ONE load level instead of span -> CSR lists -> gslot."""
+        rows = self.__dict__.get('_order_rows')
+        if rows is not None:
+            return rows
+        n, dev = self.n_active, self.device
+        if self.hip:
+            from . import _hip
+            from ._hip import ptr
+            rows = torch.empty(max(n, 1), self.ROW_INTS, dtype=torch.int32, device=dev)[:n]
+            _hip.call('mgv_plan_order_rows', n, ptr(self.order), ptr(self.in_ptr), ptr(self.in_src), ptr(self.out_ptr), ptr(self.out_dst),
+                      ptr(self.out_slot), ptr(self.gslot), ptr(rows))
+        else:
+            on = self.order.long()
+            rows = torch.full((n, self.ROW_INTS), -1, dtype=torch.int32, device=dev)
+            rows[:, 0:4] = self.order_span
+            if self.E > 0 and n > 0:
+                in0, in1 = self.in_ptr[on].long(), self.in_ptr[on + 1].long()
+                idx = in0[:, None] + torch.arange(4, device=dev)
+                ok = idx < in1[:, None]
+                rows[:, 4:8] = torch.where(ok, self.in_src[idx.clamp(max=self.E - 1)], torch.full_like(idx, -1, dtype=torch.int32))
+                o0, o1 = self.out_ptr[on].long(), self.out_ptr[on + 1].long()
+                oidx = o0[:, None] + torch.arange(self.ROW_OUT, device=dev)
+                ook = oidx < o1[:, None]
+                oc = oidx.clamp(max=self.E - 1)
+                c = torch.where(ook, self.out_dst[oc], torch.full_like(oc, -1, dtype=torch.int32))
+                sl = torch.where(ook, self.out_slot[oc], torch.full_like(oc, -1, dtype=torch.int32))
+                rows[:, 8:24] = torch.stack([c, sl], 2).reshape(n, 2 * self.ROW_OUT)
+                gc = torch.where(ook, self.gslot[c.clamp(min=0).long()], torch.full_like(oc, NO_GATE, dtype=torch.uint8))
+                rows[:, 24:26] = gc.contiguous().view(torch.int32)
+        self.__dict__['_order_rows'] = rows
+        return rows
 
     def set_levels(self, gate, forward_level, gate_ids):
         """Bucket the nodes a Model updates: level >= 1 and gate id in `gate_ids` (list, position =

@@ -670,6 +670,17 @@ def _sweep_x3(H):
 # grid barrier, in-register weight gradient).  Built, parity-tested and MEASURED in round 4: not faster than the per-level kernels at any
 # batch size (config 2: forward 2.17 vs 2.00 ms, backward 8.2 vs 7.4 ms; one graph: 0.95 / 2.80 vs 1.01 / 2.84 ms), so it is
 # opt-in (MGV_SWEEP_PERSIST=1) and the per-level kernels stay the default.
+# the level kernels read packed rows (GraphPlan.order_rows: spans + first in-edge sources + first consumers, one 128-byte line per
+# updated node) unless MGV_PACKED_ROWS=0 (then the 16-byte span rows and the CSR lists behind them)
+PACKED_ROWS = os.environ.get('MGV_PACKED_ROWS', '1') != '0'
+
+
+def _sweep_rows(plan):
+    if PACKED_ROWS:
+        return ptr(plan.order_rows), 32
+    return ptr(plan.order_span), 4
+
+
 PERSIST = os.environ.get('MGV_SWEEP_PERSIST', '0') == '1'
 
 
@@ -731,7 +742,7 @@ class FuncSweepRoundFn(torch.autograd.Function):
         zb = torch.zeros(T, 3 * H, dtype=F32, device=hsd.device)
         hf = hp.clone()                      # never-updated rows keep their state; every updated row is rewritten by its level
         if wpack is not None:
-            _hip.call('mgv_func_sweep_round_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.order_span),
+            _hip.call('mgv_func_sweep_round_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), *_sweep_rows(plan),
                       ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
                       ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(zb), ptr(ghd), ptr(hp))
         else:
@@ -767,7 +778,7 @@ class FuncSweepRoundFn(torch.autograd.Function):
             return (None, ghs, g_hprev, d_gh, grads[0], grads[1], grads[2], grads[3])
         ghs = torch.empty(N, H, dtype=F32, device=dev)
         scratch, stp, hv, ha = _sweep_bwd_prep(plan, T, H, dev)
-        _hip.call('mgv_func_sweep_round_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.order_span),
+        _hip.call('mgv_func_sweep_round_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), *_sweep_rows(plan),
                   plan.n_active, ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.slot_tiles), stp,
                   ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr), ptr(plan.out_dst), ptr(plan.out_slot),
                   ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]), ptr(ctx.wpack), ptr(par[2]), ptr(par[3]), ptr(ctx.zb),
@@ -807,7 +818,7 @@ class FuncSweepFn(torch.autograd.Function):
                       ptr(plan.order_span), ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd),
                       ptr(hf), ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]), ptr(sync), ptr(sticky))
         elif wpack is not None:
-            _hip.call('mgv_func_sweep_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), ptr(plan.order_span),
+            _hip.call('mgv_func_sweep_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), *_sweep_rows(plan),
                       ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
                       ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]))
         else:
@@ -855,7 +866,7 @@ class FuncSweepFn(torch.autograd.Function):
             return (None, ghs, *grads)
         if ctx.wpack is not None:
             scratch, stp, hv, ha = _sweep_bwd_prep(plan, T, H, dev)
-            _hip.call('mgv_func_sweep_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), ptr(plan.order_span),
+            _hip.call('mgv_func_sweep_bwd_x3', H, N, T, plan.num_levels, ctx.ltp, ptr(plan.order), *_sweep_rows(plan),
                       plan.n_active, ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.slot_tiles), stp,
                       ptr(plan.in_ptr), ptr(plan.in_src), ptr(plan.out_ptr), ptr(plan.out_dst), ptr(plan.out_slot),
                       ptr(plan.gslot), ptr(hs), ptr(hf), ptr(par[0]), ptr(ctx.wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]),

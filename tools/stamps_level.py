@@ -55,7 +55,7 @@ def main():
     hf2 = torch.empty_like(hf)
     hf2.zero_()
     rc = lib.mgv_diag_func_sweep_fwd_x3_impl(
-        H, ctypes.c_int64(N), T, plan.num_levels, ltp, P(plan.order), P(plan.order_span), P(plan.tile_start), P(plan.tile_count),
+        H, ctypes.c_int64(N), T, plan.num_levels, ltp, P(plan.order), P(plan.order_rows), 32, P(plan.tile_start), P(plan.tile_count),
         P(plan.tile_slot), P(plan.in_ptr), P(plan.in_src), P(hs), P(hf2), P(attn_u), P(wpack), P(bvc), P(bih), P(bhh), st)
     torch.cuda.synchronize()
     assert rc == 0, rc
@@ -66,7 +66,7 @@ def main():
         print('   %-44s %5.1f%%' % (name, 100 * t[:, k].sum() / tot))
     stamps.zero_()
     rc = lib.mgv_diag_func_sweep_bwd_x3_impl(
-        H, ctypes.c_int64(N), T, plan.num_levels, ltp, P(plan.order), P(plan.order_span), ctypes.c_int64(plan.n_active),
+        H, ctypes.c_int64(N), T, plan.num_levels, ltp, P(plan.order), P(plan.order_rows), 32, ctypes.c_int64(plan.n_active),
         P(plan.tile_start), P(plan.tile_count), P(plan.tile_slot), P(plan.slot_tiles), stp, P(plan.in_ptr), P(plan.in_src),
         P(plan.out_ptr), P(plan.out_dst), P(plan.out_slot), P(plan.gslot), P(hs), P(hf), P(attn_u), P(wpack), P(bvc), P(bih), P(bhh),
         P(ghf), P(ghs), P(dzb), P(alpha), P(dsc), *[P(g) for g in grads], P(scratch), ctypes.c_int64(scratch.numel()), 0, 0, None, None, None, None, None, None, None, 0, st)
