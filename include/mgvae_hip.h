@@ -489,8 +489,31 @@ int mgv_plan_pairs(int64_t N, const int32_t* in_ptr, const uint8_t* xcls, int32_
  * neighbour-colour multiset; flags[0] = 1 on any difference, flags[1] = nodes with lists beyond 48 entries, left to the caller. */
 int mgv_colour_keys(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const int64_t* f, int64_t fstride,
                     const uint8_t* xcls, int64_t* key, void* stream);
-int mgv_colour_check(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const uint8_t* xcls, const int64_t* cid,
-                     const int64_t* rep, int32_t* flags, void* stream);
+int mgv_colour_check(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const uint8_t* xcls, const int32_t* cid,
+                     const int32_t* rep, int32_t* flags, void* stream);
+/* a refinement stage's tables on the device (csrc/plan_build.hip, GraphPlan._quotient_dev): what GraphPlan.quotient composes from torch
+ * sorts / scans / gathers for CPU plans (the reference has no counterpart: it runs every half round on all N rows, digae_layer.py:257-277).
+ * sort_pairs: stable radix sort of n keys (key_bytes 4 or 8, unsigned, bits [0, end_bit)), order[] = the sorting permutation (int32). */
+int mgv_sort_pairs_temp_ints(int key_bytes, int64_t n);                                             /* a size in 4-byte units (-1: error) */
+int mgv_sort_pairs(int key_bytes, int64_t n, const void* keys_in, void* keys_out, int32_t* order, int end_bit, void* temp,
+                   int64_t temp_ints, void* stream);
+/* runs of equal sorted keys -> colours: cid[N], starts[C + 1] (buffer of N + 1), rep[C] (buffer of N), n_colours[0] = C;
+ * scratch_ints >= 2 N + N / 2048 + 66 */
+int mgv_colour_groups(int64_t N, const int64_t* skey, const int32_t* by_colour, int32_t* cid, int32_t* starts, int32_t* rep, int32_t* n_colours,
+                      int32_t* scratch, int64_t scratch_ints, void* stream);
+/* representatives' rows: rptr[C + 1] (rptr[C] = list entries), own[C] previous colour, xrep[C] feature class, n_heavy[0];
+ * scratch_ints >= C + C / 2048 + 66; then their lists in previous colours ent[] and the owning colour row[] of every entry */
+int mgv_colour_rep_rows(int64_t C, const int32_t* rep, const int32_t* nbr_ptr, const int32_t* prev, const uint8_t* xcls, int heavy_row,
+                        int32_t* rptr, int32_t* own, uint8_t* xrep, int32_t* n_heavy, int32_t* scratch, int64_t scratch_ints, void* stream);
+int mgv_colour_rep_lists(int64_t C, const int32_t* rep, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const int32_t* rptr,
+                         int32_t* ent, int32_t* row, void* stream);
+int mgv_sorted_key_counts(int64_t n, const int32_t* sorted_keys, int64_t K, int32_t* counts, void* stream);
+/* one level of mgv_seg_sum's segment tables: scan leaves work[0..3] = {segments, members, partial rows, colours with > 1 segment},
+ * fill writes seg_ptr[n_seg + 1], out_row[n_seg] (nullable) and the next level's colours (nullable pair) */
+int mgv_seg_level_work_ints(int64_t G);                                                             /* a size */
+int mgv_seg_level_scan(int64_t G, const int32_t* counts, int seg, int32_t* work, int64_t work_ints, void* stream);
+int mgv_seg_level_fill(int64_t G, int64_t n_seg, const int32_t* gid, int seg, int base, const int32_t* work, int32_t* seg_ptr, int32_t* out_row,
+                       int32_t* gid_next, int32_t* counts_next, void* stream);
 
 #ifdef __cplusplus
 }

@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void k_colour_keys(int64_t N, const int32_t* p
 }
 
 __global__ __launch_bounds__(256) void k_colour_check(int64_t N, const int32_t* ptr, const int32_t* idx, const int32_t* prev, const uint8_t* xcls,
-                                                      const int64_t* cid, const int64_t* rep, int32_t* flags) {
+                                                      const int32_t* cid, const int32_t* rep, int32_t* flags) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const int64_t r = rep[cid[i]];
@@ -382,6 +382,77 @@ __global__ __launch_bounds__(256) void k_colour_check(int64_t N, const int32_t* 
         for (int m = 0; m < d; ++m) { na += prev[idx[a0 + m]] == c; nb += prev[idx[b0 + m]] == c; }
         if (na != nb) { flags[0] = 1; return; }
     }
+}
+
+// ---- a refinement stage's tables from the sorted keys, on the device (GraphPlan._quotient_dev).
+// runs of equal keys -> colours: first[i] marks a run's first sorted position, its exclusive scan numbers the runs
+__global__ __launch_bounds__(256) void k_run_first(int64_t N, const int64_t* skey, int32_t* first) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) first[i] = (i == 0 || skey[i] != skey[i - 1]) ? 1 : 0;
+}
+// pos = exclusive scan of first (pos[N] = number of runs): colour of sorted position i = pos[i] + first[i] - 1
+__global__ __launch_bounds__(256) void k_run_assign(int64_t N, const int32_t* first, const int32_t* pos, const int32_t* by_colour, int32_t* cid,
+                                                    int32_t* starts, int32_t* rep, int32_t* n_colours) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int f = first[i], c = pos[i] + f - 1, v = by_colour[i];
+    cid[v] = c;
+    if (f) { starts[c] = (int32_t)i; rep[c] = v; }
+    if (i == N - 1) { starts[c + 1] = (int32_t)N; n_colours[0] = c + 1; }
+}
+// per colour: its representative's degree, previous colour and feature class; heavy rows counted
+__global__ __launch_bounds__(256) void k_rep_rows(int64_t C, const int32_t* rep, const int32_t* ptr, const int32_t* prev, const uint8_t* xcls, int heavy_row,
+                                                  int32_t* dr, int32_t* own, uint8_t* xrep, int32_t* n_heavy) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r = rep[c], d = ptr[r + 1] - ptr[r];
+    dr[c] = d; own[c] = prev[r]; xrep[c] = xcls[r];
+    if (d > heavy_row) atomicAdd(n_heavy, 1);
+}
+// a representative's list in previous colours, and the colour that owns every list entry
+__global__ __launch_bounds__(256) void k_rep_lists(int64_t C, const int32_t* rep, const int32_t* ptr, const int32_t* idx, const int32_t* prev,
+                                                   const int32_t* rptr, int32_t* ent, int32_t* row) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int r = rep[c], e0 = ptr[r], d = ptr[r + 1] - e0, o = rptr[c];
+    for (int k = 0; k < d; ++k) { ent[o + k] = prev[idx[e0 + k]]; row[o + k] = (int32_t)c; }
+}
+// members per key of an ascending key array: counts[k] = lower_bound(k + 1) - lower_bound(k)
+__global__ __launch_bounds__(256) void k_sorted_key_counts(int64_t n, const int32_t* sorted, int64_t K, int32_t* counts) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (sorted[m] < k) lo = m + 1; else hi = m; }
+    const int64_t a = lo;
+    hi = n;
+    while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (sorted[m] <= k) lo = m + 1; else hi = m; }
+    counts[k] = (int32_t)(lo - a);
+}
+// segment tables of mgv_seg_sum, one level: colour g with counts[g] members is cut into nseg = max(1, ceil(counts / seg)) segments;
+// a colour with more than one leaves partial rows (summed by the next level)
+__global__ __launch_bounds__(256) void k_seg_level_counts(int64_t G, const int32_t* counts, int seg, int32_t* nseg, int32_t* part, int32_t* multi) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= G) return;
+    const int n = counts[g], s = n > seg ? (n + seg - 1) / seg : 1;
+    nseg[g] = s; part[g] = s > 1 ? s : 0; multi[g] = s > 1;
+}
+__global__ __launch_bounds__(64) void k_seg_level_totals(int64_t G, const int32_t* first, const int32_t* start, const int32_t* pfirst, const int32_t* midx,
+                                                         int32_t* totals) {
+    if (threadIdx.x == 0) { totals[0] = first[G]; totals[1] = start[G]; totals[2] = pfirst[G]; totals[3] = midx[G]; }
+}
+__global__ __launch_bounds__(256) void k_seg_level_fill(int64_t G, int64_t n_seg, const int32_t* gid, int seg, int base, const int32_t* nseg,
+                                                        const int32_t* first, const int32_t* start, const int32_t* pfirst, const int32_t* midx,
+                                                        int32_t* seg_ptr, int32_t* out_row, int32_t* gid_next, int32_t* counts_next) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < n_seg) {
+        int64_t lo = 0, hi = G;                     // the colour g with first[g] <= t < first[g + 1] (every colour has >= 1 segment)
+        while (hi - lo > 1) { const int64_t m = (lo + hi) >> 1; if (first[m] <= t) lo = m; else hi = m; }
+        const int g = (int)lo, j = (int)(t - first[g]);
+        seg_ptr[t] = start[g] + seg * j;
+        if (out_row) out_row[t] = nseg[g] > 1 ? base + pfirst[g] + j : (gid ? gid[g] : g);
+        if (t == 0) seg_ptr[n_seg] = start[G];
+    }
+    if (t < G && nseg[t] > 1 && gid_next) { gid_next[midx[t]] = gid ? gid[t] : (int32_t)t; counts_next[midx[t]] = nseg[t]; }
 }
 
 }  // namespace mgv
@@ -621,10 +692,84 @@ extern "C" int mgv_colour_keys(int64_t N, const int32_t* nbr_ptr, const int32_t*
     hipLaunchKernelGGL(k_colour_keys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), N, nbr_ptr, nbr_idx, prev, f, fstride, xcls, key);
     MGV_LAUNCH_RET();
 }
-extern "C" int mgv_colour_check(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const uint8_t* xcls, const int64_t* cid,
-                                const int64_t* rep, int32_t* flags, void* stream) {
+extern "C" int mgv_colour_check(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const uint8_t* xcls, const int32_t* cid,
+                                const int32_t* rep, int32_t* flags, void* stream) {
     MGV_CHECK_ARG(N >= 0 && nbr_ptr && prev && xcls && cid && rep && flags);
     if (N == 0) return MGV_OK;
     hipLaunchKernelGGL(k_colour_check, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), N, nbr_ptr, nbr_idx, prev, xcls, cid, rep, flags);
+    MGV_LAUNCH_RET();
+}
+
+/* ---- a colour-refinement stage's tables built on the device (GraphPlan._quotient_dev; the torch composition of the same tables stays in
+ * GraphPlan.quotient for CPU plans, and the GPU tests compare the two field by field).
+ * groups: from the sorted keys skey[N] and the sorting permutation by_colour[N]: cid[v] = colour (rank of its key's run), starts[C + 1] = first
+ * sorted position of every run (starts[C] = N), rep[c] = first member, n_colours[0] = C.  starts / rep hold N + 1 / N ints (C is not known to
+ * the host yet); scratch: 2 N + N / 2048 + 66 ints. */
+extern "C" int mgv_colour_groups(int64_t N, const int64_t* skey, const int32_t* by_colour, int32_t* cid, int32_t* starts, int32_t* rep, int32_t* n_colours,
+                                 int32_t* scratch, int64_t scratch_ints, void* stream) {
+    MGV_CHECK_ARG(N >= 1 && skey && by_colour && cid && starts && rep && n_colours && scratch && scratch_ints >= 2 * N + N / kScanItems + 66);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t* first = scratch;
+    int32_t* pos = scratch + N;
+    int32_t* scan = pos + N + 1;
+    const unsigned nb = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(k_run_first, dim3(nb), dim3(256), 0, st, N, skey, first);
+    const int rc = scan_exclusive(N, first, pos, scan, st);
+    if (rc != MGV_OK) return rc;
+    hipLaunchKernelGGL(k_run_assign, dim3(nb), dim3(256), 0, st, N, first, pos, by_colour, cid, starts, rep, n_colours);
+    MGV_LAUNCH_RET();
+}
+/* rep_rows: per colour its representative's previous colour own[C], feature class xrep[C] and list offsets rptr[C + 1] (rptr[C] = number of
+ * list entries), n_heavy[0] = colours whose list is longer than heavy_row.  scratch: C + C / 2048 + 66 ints.
+ * rep_lists: ent[rptr[c] + k] = previous colour of the representative's k-th neighbour, row[...] = c. */
+extern "C" int mgv_colour_rep_rows(int64_t C, const int32_t* rep, const int32_t* nbr_ptr, const int32_t* prev, const uint8_t* xcls, int heavy_row,
+                                   int32_t* rptr, int32_t* own, uint8_t* xrep, int32_t* n_heavy, int32_t* scratch, int64_t scratch_ints, void* stream) {
+    MGV_CHECK_ARG(C >= 1 && rep && nbr_ptr && prev && xcls && rptr && own && xrep && n_heavy && scratch && scratch_ints >= C + C / kScanItems + 66);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipMemsetAsync(n_heavy, 0, sizeof(int32_t), st);
+    hipLaunchKernelGGL(k_rep_rows, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, C, rep, nbr_ptr, prev, xcls, heavy_row, scratch, own, xrep, n_heavy);
+    return scan_exclusive(C, scratch, rptr, scratch + C, st);
+}
+extern "C" int mgv_colour_rep_lists(int64_t C, const int32_t* rep, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const int32_t* rptr,
+                                    int32_t* ent, int32_t* row, void* stream) {
+    MGV_CHECK_ARG(C >= 1 && rep && nbr_ptr && prev && rptr && ent && row);
+    hipLaunchKernelGGL(k_rep_lists, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), C, rep, nbr_ptr, nbr_idx, prev, rptr, ent, row);
+    MGV_LAUNCH_RET();
+}
+/* members per key k in [0, K) of an ASCENDING key array */
+extern "C" int mgv_sorted_key_counts(int64_t n, const int32_t* sorted_keys, int64_t K, int32_t* counts, void* stream) {
+    MGV_CHECK_ARG(n >= 0 && K >= 1 && counts && (n == 0 || sorted_keys));
+    hipLaunchKernelGGL(k_sorted_key_counts, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), n, sorted_keys, K, counts);
+    MGV_LAUNCH_RET();
+}
+/* One level of mgv_seg_sum's segment tables (GraphPlan.class_sum_levels) for G colours with counts[G] members each, cut into segments of <= seg.
+ * scan: work[0..3] = {segments, members, partial rows this level leaves, colours with more than one segment}; the rest of `work`
+ * (mgv_seg_level_work_ints(G) ints) carries the per-colour scans to `fill`, which writes seg_ptr[n_seg + 1], out_row[n_seg] (NULL: segment s
+ * writes row s) — a colour's only segment writes row gid[g] (NULL gid: g), a partial row base + its running number — and the next level's
+ * colours gid_next / counts_next (NULL when no colour has more than one segment). */
+extern "C" int mgv_seg_level_work_ints(int64_t G) { return (int)(4 + 3 * G + 4 * (G + 1) + G / kScanItems + 66); }
+extern "C" int mgv_seg_level_scan(int64_t G, const int32_t* counts, int seg, int32_t* work, int64_t work_ints, void* stream) {
+    MGV_CHECK_ARG(G >= 1 && counts && seg >= 2 && work && work_ints >= mgv_seg_level_work_ints(G));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t* nseg = work + 4; int32_t* part = nseg + G; int32_t* multi = part + G;
+    int32_t* first = multi + G; int32_t* start = first + G + 1; int32_t* pfirst = start + G + 1; int32_t* midx = pfirst + G + 1;
+    int32_t* scan = midx + G + 1;
+    hipLaunchKernelGGL(k_seg_level_counts, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, G, counts, seg, nseg, part, multi);
+    int rc = scan_exclusive(G, nseg, first, scan, st);
+    if (rc == MGV_OK) rc = scan_exclusive(G, counts, start, scan, st);
+    if (rc == MGV_OK) rc = scan_exclusive(G, part, pfirst, scan, st);
+    if (rc == MGV_OK) rc = scan_exclusive(G, multi, midx, scan, st);
+    if (rc != MGV_OK) return rc;
+    hipLaunchKernelGGL(k_seg_level_totals, dim3(1), dim3(64), 0, st, G, first, start, pfirst, midx, work);
+    MGV_LAUNCH_RET();
+}
+extern "C" int mgv_seg_level_fill(int64_t G, int64_t n_seg, const int32_t* gid, int seg, int base, const int32_t* work, int32_t* seg_ptr, int32_t* out_row,
+                                  int32_t* gid_next, int32_t* counts_next, void* stream) {
+    MGV_CHECK_ARG(G >= 1 && n_seg >= G && work && seg_ptr && ((gid_next == nullptr) == (counts_next == nullptr)));
+    const int32_t* nseg = work + 4; const int32_t* first = nseg + 3 * G; const int32_t* start = first + G + 1; const int32_t* pfirst = start + G + 1;
+    const int32_t* midx = pfirst + G + 1;
+    const int64_t threads = n_seg > G ? n_seg : G;
+    hipLaunchKernelGGL(k_seg_level_fill, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), G, n_seg, gid, seg, base, nseg,
+                       first, start, pfirst, midx, seg_ptr, out_row, gid_next, counts_next);
     MGV_LAUNCH_RET();
 }

@@ -319,7 +319,10 @@ class GraphPlan:
         N, dev = self.N, self.device
         stages = []
         self._check_status()                 # (edge ids outside [0, N) raise here, before the lists are read)
-        if (force or N >= self.QUOTIENT_MIN_NODES) and self.E > 0:
+        if self.hip and self.QUOTIENT_DEVICE and not force:
+            if N >= self.QUOTIENT_MIN_NODES and self.E > 0:
+                stages = self._quotient_dev(xcls, int(max_stages))
+        elif (force or N >= self.QUOTIENT_MIN_NODES) and self.E > 0:
             i64 = dict(dtype=torch.int64, device=dev)
             gen = torch.Generator(device=dev)
             gen.manual_seed(0x5EED5)
@@ -366,7 +369,7 @@ class GraphPlan:
                 n_long = 1
                 if self.hip:
                     flags = torch.zeros(2, dtype=torch.int32, device=dev)
-                    _hip.call('mgv_colour_check', N, ptr(p), ptr(idx), ptr(prev32), ptr(xcls), ptr(inv), ptr(rep), ptr(flags))
+                    _hip.call('mgv_colour_check', N, ptr(p), ptr(idx), ptr(prev32), ptr(xcls), ptr(inv.to(torch.int32)), ptr(rep.to(torch.int32)), ptr(flags))
                     bad, n_long = flags.tolist()
                     if bad:
                         break
@@ -374,13 +377,7 @@ class GraphPlan:
                     owner = owners.get(rev)
                     if owner is None:
                         owner = owners[rev] = torch.repeat_interleave(node, deg) if rev else self.in_dst.long()
-                    pn = prev[il]
-                    ri = rep[inv]
-                    same = (xc == xc[ri]) & (prev == prev[ri]) & (deg == deg[ri])
-                    sorted_col = torch.sort(owner * (Cp + 1) + pn).values - owner * (Cp + 1)      # each node's list, colours ascending
-                    k_in_list = torch.arange(owner.numel(), **i64) - pl[:-1][owner]
-                    lists_same = sorted_col == sorted_col[(pl[:-1][ri[owner]] + k_in_list).clamp_(max=max(owner.numel() - 1, 0))]
-                    if not (bool(same.all()) and bool(lists_same.all())):
+                    if not self._colour_lists_equal(pl, il, owner, prev, inv, rep, xc, Cp):
                         break
                 dr = deg[rep]
                 rptr = torch.zeros(C + 1, **i64)
@@ -413,6 +410,141 @@ class GraphPlan:
             if stages:
                 stages[-1]['sum_levels'] = self.class_sum_levels(stages[-1]['cid'], stages[-1]['C'], presorted=last_sorted)
         cache[1][int(max_stages)] = stages
+        return stages
+
+    def _colour_lists_equal(self, pl, il, owner, prev, inv, rep, xc, Cp):
+        """Exact check of a grouping by sorting: every node has its representative's feature class, previous colour, degree and
+        neighbour-colour multiset (both lists sorted by colour and compared entry by entry).  All arguments int64."""
+        deg = pl[1:] - pl[:-1]
+        pn = prev[il]
+        ri = rep[inv]
+        same = (xc == xc[ri]) & (prev == prev[ri]) & (deg == deg[ri])
+        sorted_col = torch.sort(owner * (Cp + 1) + pn).values - owner * (Cp + 1)      # each node's list, colours ascending
+        k_in_list = torch.arange(owner.numel(), dtype=torch.int64, device=self.device) - pl[:-1][owner]
+        lists_same = sorted_col == sorted_col[(pl[:-1][ri[owner]] + k_in_list).clamp_(max=max(owner.numel() - 1, 0))]
+        return bool(same.all()) and bool(lists_same.all())
+
+    QUOTIENT_DEVICE = True      # hip plans: a stage's tables by the plan builder's kernels (_quotient_dev); False: the torch composition below
+
+    def _sort_by_key_dev(self, keys, n, K):
+        """(order int32 [n], members per key int32 [K]) of a STABLE sort of n int32 keys in [0, K): the counting sort of the tile
+        builder while its (key, block) histogram stays small, else a radix sort over the keys' bits."""
+        from . import _hip
+        from ._hip import ptr
+        i32 = dict(dtype=torch.int32, device=self.device)
+        if n == 0:
+            return torch.zeros(0, **i32), torch.zeros(K, **i32)
+        order = torch.empty(n, **i32)
+        if K <= 8192 and K * ((n + 1023) // 1024) <= 4 * n + 65536:
+            ks = torch.empty(K + 1, **i32)
+            n_s = _hip.call_value('mgv_count_sort_scratch_ints', n, K)
+            scratch = torch.empty(n_s, **i32)
+            _hip.call('mgv_count_sort_i32', n, ptr(keys), K, ptr(order), ptr(ks), ptr(scratch), n_s)
+            return order, ks[1:] - ks[:-1]
+        sk = torch.empty(n, **i32)
+        t_i = _hip.call_value('mgv_sort_pairs_temp_ints', 4, n)
+        temp = torch.empty(t_i, **i32)
+        _hip.call('mgv_sort_pairs', 4, n, ptr(keys), ptr(sk), ptr(order), max((K - 1).bit_length(), 1), ptr(temp), t_i)
+        counts = torch.empty(K, **i32)
+        _hip.call('mgv_sorted_key_counts', n, ptr(sk), K, ptr(counts))
+        return order, counts
+
+    def _class_sum_levels_dev(self, counts, C, seg=64):
+        """class_sum_levels' tables from the members per colour (int32 [C]) by the plan builder's kernels: per level one scan pass
+        (segments, members, partial rows, colours going on), one read-back of the four totals, one fill pass."""
+        from . import _hip
+        from ._hip import ptr
+        i32 = dict(dtype=torch.int32, device=self.device)
+        counts0 = counts
+        levels = []
+        gid, G = None, C
+        base, src_row = C, 0
+        while True:
+            w_i = _hip.call_value('mgv_seg_level_work_ints', G)
+            work = torch.empty(w_i, **i32)
+            _hip.call('mgv_seg_level_scan', G, ptr(counts), seg, ptr(work), w_i)
+            total, _, n_partial, g_next = work[:4].tolist()
+            sp = torch.empty(total + 1, **i32)
+            out_row = None if (n_partial == 0 and G == C and base == C) else torch.empty(total, **i32)
+            gid_n = torch.empty(g_next, **i32) if g_next else None
+            counts_n = torch.empty(g_next, **i32) if g_next else None
+            _hip.call('mgv_seg_level_fill', G, total, ptr(gid), seg, base, ptr(work), ptr(sp), ptr(out_row), ptr(gid_n), ptr(counts_n))
+            levels.append((total, sp, out_row, src_row))
+            if n_partial == 0:
+                return dict(C=C, rows=base, levels=levels, counts=counts0)
+            gid, counts, G = gid_n, counts_n, g_next
+            src_row, base = base, base + n_partial
+
+    def _quotient_dev(self, xcls, max_stages):
+        """The stages of `quotient` with every table built by the plan builder's kernels (csrc/plan_build.hip, radix_sort.hip): per
+        stage the grouping keys, ONE radix sort of them (the permutation as int32), runs -> colours / representatives, the exact
+        check, the representatives' lists in previous colours, and the segment tables of the colour-level sums (stable sort by
+        previous colour + per-level scans).  Host read-backs per stage: the colour count, the check's flags, the list length, and
+        four totals per table level.  Same numbering, same tables as the torch composition (GPU test, field by field)."""
+        from . import _hip
+        from ._hip import ptr
+        N, dev = self.N, self.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        i64 = dict(dtype=torch.int64, device=dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0x5EED5)
+        stages = []
+        prev32, Cp = torch.zeros(N, **i32), 1
+        t_sort = _hip.call_value('mgv_sort_pairs_temp_ints', 8, N)
+        n_grp = 2 * N + N // 2048 + 66
+        last = None
+        for t_ in range(1, max_stages + 1):
+            rev = t_ % 2 == 0
+            p, idx = self.csr(rev)
+            f = torch.randint(1, 1 << 62, (3, Cp + 1), generator=gen, **i64)
+            mix, skey = torch.empty(N, **i64), torch.empty(N, **i64)
+            by_colour, temp = torch.empty(N, **i32), torch.empty(t_sort, **i32)
+            _hip.call('mgv_colour_keys', N, ptr(p), ptr(idx), ptr(prev32), ptr(f), Cp + 1, ptr(xcls), ptr(mix))
+            _hip.call('mgv_sort_pairs', 8, N, ptr(mix), ptr(skey), ptr(by_colour), 63, ptr(temp), t_sort)
+            cid, starts, rep = torch.empty(N, **i32), torch.empty(N + 1, **i32), torch.empty(N, **i32)
+            flags = torch.zeros(3, **i32)                       # [grouping refuted, lists too long for the kernel's check, colours]
+            scratch = torch.empty(n_grp, **i32)
+            _hip.call('mgv_colour_groups', N, ptr(skey), ptr(by_colour), ptr(cid), ptr(starts), ptr(rep), ptr(flags[2:]), ptr(scratch), n_grp)
+            C = int(flags[2].item())
+            if C * self.QUOTIENT_FRACTION > N:
+                break
+            _hip.call('mgv_colour_check', N, ptr(p), ptr(idx), ptr(prev32), ptr(xcls), ptr(cid), ptr(rep), ptr(flags))
+            bad, n_long = flags[:2].tolist()
+            if bad:
+                break
+            if n_long:                       # lists longer than the kernel compares pairwise: the sort-based check
+                pl, il = p.long(), idx.long()
+                owner = torch.repeat_interleave(torch.arange(N, **i64), pl[1:] - pl[:-1]) if rev else self.in_dst.long()
+                if not self._colour_lists_equal(pl, il, owner, prev32.long(), cid.long(), rep[:C].long(), xcls.long(), Cp):
+                    break
+            small = torch.empty(C + 2, **i32)                   # rptr [C + 1], then the heavy-row count
+            rptr, own32, xrep = small[:C + 1], torch.empty(C, **i32), torch.empty(C, dtype=torch.uint8, device=dev)
+            n_rr = C + C // 2048 + 66
+            scratch = torch.empty(n_rr, **i32)
+            _hip.call('mgv_colour_rep_rows', C, ptr(rep), ptr(p), ptr(prev32), ptr(xcls), self.HEAVY_ROW, ptr(rptr), ptr(own32), ptr(xrep),
+                      ptr(small[C + 1:]), ptr(scratch), n_rr)
+            n_ent, n_heavy = small[C:].tolist()
+            ent, row = torch.empty(max(n_ent, 1), **i32), torch.empty(max(n_ent, 1), **i32)
+            if n_ent:
+                _hip.call('mgv_colour_rep_lists', C, ptr(rep), ptr(p), ptr(idx), ptr(prev32), ptr(rptr), ptr(ent), ptr(row))
+            else:
+                ent.zero_()
+            heavy = (torch.nonzero((rptr[1:] - rptr[:-1]) > self.HEAVY_ROW).reshape(-1).to(torch.int32) if n_heavy
+                     else torch.zeros(0, **i32))
+            own_o, own_counts = self._sort_by_key_dev(own32, C, Cp)
+            ent_o, ent_counts = self._sort_by_key_dev(ent, n_ent, Cp)
+            stages.append(dict(C=C, cid=cid, rev=rev, ptr=rptr, idx=(ent + C) if n_ent else ent, ent_idx=ent,
+                               own=own32.long(), own32=own32, xcls=xrep, heavy=(int(n_heavy), heavy),
+                               own_rows=own_o, own_levels=self._class_sum_levels_dev(own_counts, Cp),
+                               ent_rows=row.index_select(0, ent_o) if n_ent else ent, ent_levels=self._class_sum_levels_dev(ent_counts, Cp)))
+            prev32, Cp = cid, C
+            last = (by_colour, starts)
+            if C * self.QUOTIENT_GROWTH * self.QUOTIENT_FRACTION > N:
+                break                        # colours multiply per half round: the next one would not qualify
+        if stages:
+            by_colour, starts = last
+            C = stages[-1]['C']
+            stages[-1]['sum_levels'] = (by_colour, self._class_sum_levels_dev(starts[1:C + 1] - starts[:C], C))
         return stages
 
     def assemble_quotient(self, parts, node_off, max_stages):

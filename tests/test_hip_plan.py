@@ -41,7 +41,7 @@ def _same(ref, got, names):
 
 
 CSR = ['in_ptr', 'in_src', 'in_dst', 'out_ptr', 'out_dst', 'out_slot']
-LEVELS = ['gslot', 'level', 'num_levels', 'order', 'order_span', 'tile_start', 'tile_count', 'tile_slot', 'slot_tiles', 'slot_tile_ptr',
+LEVELS = ['gslot', 'level', 'num_levels', 'order', 'order_span', 'order_rows', 'tile_start', 'tile_count', 'tile_slot', 'slot_tiles', 'slot_tile_ptr',
           'level_tile_ptr', 'num_tiles', 'n_active', 'num_slots']
 
 
@@ -264,6 +264,69 @@ def test_device_colour_refinement_equals_the_host_one():
         assert len(pairs) == h['C']                      # one-to-one: the same partition (numbering may differ)
 
 
+def _same_tables(a, b, name):
+    assert a['C'] == b['C'] and a['rows'] == b['rows'] and len(a['levels']) == len(b['levels']), name
+    for (na, spa, ora, sra), (nb, spb, orb, srb) in zip(a['levels'], b['levels']):
+        assert na == nb and sra == srb and torch.equal(spa, spb), name
+        assert (ora is None) == (orb is None) and (ora is None or torch.equal(ora, orb)), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['aig_hubs', 'xmg', 'long_runs'])
+def test_device_built_stage_tables_equal_the_torch_composition(case):
+    """GraphPlan._quotient_dev (every table of a refinement stage by the plan builder's kernels: radix sort of the keys, runs ->
+    colours, representatives' lists, stable sort by previous colour, segment tables level by level) against the torch composition
+    of the same tables in GraphPlan.quotient, on the same device plan: the same colour NUMBERING and every table equal, field by
+    field.  Cases: twin hubs whose lists go to the sort-based check; five gate types; few colours with hundreds of thousands of
+    members (several table levels, partial rows, the radix path of the stable sort)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from deepgate import synthetic as syn
+    from deepgate.graph_plan import GraphPlan
+    dev = torch.device('cuda:0')
+    stages_n, frac = 4, 1.5
+    if case == 'aig_hubs':
+        a = syn.collate([syn.make_graph('aig', 256 + 64 * 40, 40, 21 + i, n_inputs=256) for i in range(3)])
+        ei = a['edge_index']
+        later = np.nonzero(a['forward_level'] >= 2)[0]
+        rng = np.random.Generator(np.random.PCG64(1))
+        extra = [np.stack([np.full(80, hub), rng.choice(later, size=80, replace=False)]) for hub in (3, 7)]
+        ei = np.unique(np.concatenate([ei] + extra, axis=1), axis=1)
+    elif case == 'xmg':
+        a = syn.collate([syn.make_graph('xmg', 300 + 50 * 60, 50, 5 + i, n_inputs=300) for i in range(4)])
+        ei = a['edge_index']
+    else:
+        a = syn.collate([syn.make_graph('aig', 4096 + 30 * 8192, 30, 3 + i, n_inputs=4096) for i in range(2)])
+        ei, stages_n, frac = a['edge_index'], 5, 1.2
+    n = a['num_nodes']
+    xcls = torch.from_numpy(a['x'][:, 1].astype('uint8')).to(dev)
+    plan = GraphPlan(torch.from_numpy(ei).to(dev), n)
+    assert plan.hip
+    old = GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES, GraphPlan.QUOTIENT_DEVICE
+    GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES = frac, 1
+    try:
+        GraphPlan.QUOTIENT_DEVICE = True
+        got = plan.quotient(xcls, stages_n)
+        plan._quotient = None
+        GraphPlan.QUOTIENT_DEVICE = False
+        ref = plan.quotient(xcls, stages_n)
+    finally:
+        GraphPlan.QUOTIENT_FRACTION, GraphPlan.QUOTIENT_MIN_NODES, GraphPlan.QUOTIENT_DEVICE = old
+    assert len(got) == len(ref) >= (2 if case == 'xmg' else 3)
+    if case == 'long_runs':
+        assert len(ref[0]['own_levels']['levels']) + len(ref[-1]['sum_levels'][1]['levels']) > 2       # multi-level tables are in play
+    for k, (g, r) in enumerate(zip(got, ref)):
+        assert g['C'] == r['C'] and g['rev'] == r['rev'] and g['heavy'][0] == r['heavy'][0], k
+        for name in ('cid', 'ptr', 'idx', 'ent_idx', 'own', 'own32', 'xcls', 'own_rows', 'ent_rows'):
+            assert g[name].dtype == r[name].dtype and torch.equal(g[name], r[name]), (k, name)
+        assert torch.equal(g['heavy'][1], r['heavy'][1]), k
+        _same_tables(g['own_levels'], r['own_levels'], (k, 'own_levels'))
+        _same_tables(g['ent_levels'], r['ent_levels'], (k, 'ent_levels'))
+        assert ('sum_levels' in g) == ('sum_levels' in r) == (k == len(ref) - 1)
+    assert torch.equal(got[-1]['sum_levels'][0], ref[-1]['sum_levels'][0])
+    _same_tables(got[-1]['sum_levels'][1], ref[-1]['sum_levels'][1], 'sum_levels')
+
+
 @pytest.mark.gpu
 def test_colour_check_rejects_a_wrong_grouping():
     """mgv_colour_check is what makes the quotient stages exact: a grouping that merges nodes with different neighbour-colour
@@ -282,7 +345,7 @@ def test_colour_check_rejects_a_wrong_grouping():
 
     def check(cid, rep):
         flags = torch.zeros(2, dtype=torch.int32, device=dev)
-        cid_t, rep_t = torch.tensor(cid, device=dev), torch.tensor(rep, device=dev)      # (kept alive across the launch)
+        cid_t, rep_t = torch.tensor(cid, dtype=torch.int32, device=dev), torch.tensor(rep, dtype=torch.int32, device=dev)      # (kept alive across the launch)
         _hip.call('mgv_colour_check', 8, ptr(plan.in_ptr), ptr(plan.in_src), ptr(prev), ptr(xcls), ptr(cid_t), ptr(rep_t), ptr(flags))
         return flags.tolist()
     good = ([0, 0, 1, 1, 2, 2, 3, 4], [0, 2, 4, 6, 7])            # 4 and 5 share a colour, 6 and 7 have their own

@@ -124,3 +124,53 @@ def test_persistent_sweep_kernels_match_the_per_level_kernels(T, levels, per):
         scale = float(c.abs().max())
         assert scale > 0, name
         assert float((a - c).abs().max()) <= 2e-5 * scale, (name, float((a - c).abs().max()), scale)
+
+
+@pytest.mark.parametrize('T,levels,per', [(5, 9, 75), (2, 40, 200)])
+def test_packed_sweep_rows_and_span_rows_give_the_same_sweep(T, levels, per):
+    """The level kernels read a tile's lists either from packed 128-byte rows (GraphPlan.order_rows, the product default: spans,
+    first 4 sources, first 8 consumers) or from 16-byte span rows and the CSR lists behind them (MGV_PACKED_ROWS=0: 16 consumers
+    staged).  Same graph with fan-outs past both caps: the forward is bit-identical, the backward sums a node's consumers in the
+    same order up to where the tail begins — to the rounding of those sums."""
+    dev = _dev()
+    from deepgate import ops
+    from deepgate.graph_plan import GraphPlan
+    if ops.PRECISION != 'x3':
+        pytest.skip('bf16x3 mode only')
+    H = 64
+    rng = np.random.default_rng(5 + T)
+    ei, gate, level, n = _graph(rng, n_in=40, levels=levels, per=per, T=T, hub_fanout=min(50, levels * per // 2), big_fanin=min(7, 30))
+    # two UPDATED gates of level 1 that drive many later gates: consumer lists past the 8 a packed row holds and past the 16 staged otherwise
+    later = np.arange(40 + 2 * per, n)
+    extra = []
+    for v, want in ((40, 33), (42, 12)):
+        has = set(ei[1][ei[0] == v].tolist())
+        pool = np.array([c for c in later if c not in has])
+        extra.append(np.stack([np.full(want - len(has), v), rng.choice(pool, size=want - len(has), replace=False)]))
+    ei = np.unique(np.concatenate([ei] + extra, axis=1), axis=1)
+    plan = GraphPlan(torch.from_numpy(ei).to(dev), n)
+    plan.set_levels(torch.from_numpy(gate).to(dev), torch.from_numpy(level).to(dev), list(range(1, T + 1)))
+    deg = (plan.out_ptr[1:] - plan.out_ptr[:-1])[plan.order.long()]
+    assert int((deg > 16).sum()) > 0 and int(((deg > 8) & (deg <= 16)).sum()) > 0      # both tails are exercised
+    torch.manual_seed(H + T)
+    hs0 = torch.randn(n, H, device=dev)
+    par0 = [torch.randn(T, 2 * H, device=dev) * 0.3, torch.randn(T, 3 * H, 2 * H, device=dev) * 0.15,
+            torch.randn(T, 3 * H, device=dev) * 0.1, torch.randn(T, 3 * H, device=dev) * 0.1, torch.randn(T, 3 * H, device=dev) * 0.1]
+    ghf = torch.randn(n, H, device=dev)
+    results = []
+    old = ops.PACKED_ROWS
+    try:
+        for packed in (True, False):
+            ops.PACKED_ROWS = packed
+            hs = hs0.clone().requires_grad_(True)
+            par = [p.clone().requires_grad_(True) for p in par0]
+            hf = ops.FuncSweepFn.apply(plan, hs, *par)
+            (hf * ghf).sum().backward()
+            results.append([hf.detach()] + [hs.grad] + [p.grad for p in par])
+    finally:
+        ops.PACKED_ROWS = old
+    assert torch.equal(results[0][0], results[1][0])
+    for name, a, b in zip(['hf', 'd hs', 'd attn_u', 'd Wvc', 'd bvc', 'd bih', 'd bhh'], *results):
+        scale = float(b.abs().max())
+        assert scale > 0, name
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (name, float((a - b).abs().max()), scale)

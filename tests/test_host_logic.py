@@ -409,6 +409,33 @@ def test_persistent_sweep_roles_cover_every_slot_and_fit_the_grid():
     assert plan.persist_roles(T - 1) is None                                    # fewer workgroups than slots with tiles
 
 
+def test_packed_sweep_rows_name_the_first_sources_and_consumers_of_every_updated_node():
+    """GraphPlan.order_rows (the 128-byte rows the level kernels read): per updated node, in sweep order, the CSR spans, the first 4
+    in-edge sources, the first 8 consumers with their slot in the consumer's in-list and the consumer's aggregator slot; -1 / 255
+    beyond a node's lists."""
+    g = [syn.make_graph('xmg', 12 + 12 * 40, 12, 7 + i, n_inputs=12) for i in range(2)]
+    a = syn.collate(g)
+    plan = GraphPlan(torch.from_numpy(a['edge_index']), a['num_nodes'])
+    plan.set_levels(torch.from_numpy(a['gate']), torch.from_numpy(a['forward_level']), [1, 2, 3, 4, 5])
+    rows = plan.order_rows.numpy()
+    assert rows.shape == (plan.n_active, 32) and rows.dtype == np.int32
+    ip, isrc, op, od, osl, gs = (getattr(plan, n).numpy() for n in ('in_ptr', 'in_src', 'out_ptr', 'out_dst', 'out_slot', 'gslot'))
+    assert max(op[1:] - op[:-1]) > 8                         # some consumer list runs past the packed row
+    for i, v in enumerate(plan.order.numpy()):
+        r = rows[i]
+        assert list(r[:4]) == [ip[v], ip[v + 1], op[v], op[v + 1]]
+        want_in = list(isrc[ip[v]:ip[v + 1]][:4])
+        assert list(r[4:8]) == want_in + [-1] * (4 - len(want_in))
+        cons = list(range(op[v], op[v + 1]))[:8]
+        pairs = [x for e in cons for x in (od[e], osl[e])]
+        assert list(r[8:24]) == pairs + [-1] * (16 - len(pairs))
+        gc = [gs[od[e]] for e in cons]
+        assert list(r[24:26].view(np.uint8)) == gc + [255] * (8 - len(gc))
+        assert np.all(r[26:] == -1)
+        for e in cons:                                       # the pair really is that edge seen from the consumer
+            assert isrc[osl[e]] == v
+
+
 def _run_seg_tables(levels, items_value):
     """Run mgv_seg_sum's tables on one number per item: the buffer of `rows` sums (every row written exactly once)."""
     buf = [None] * levels['rows']
