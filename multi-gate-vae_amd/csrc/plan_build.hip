@@ -237,10 +237,17 @@ __global__ __launch_bounds__(256) void k_bucket_keys(int64_t N, int T, const flo
         key[n] = active ? (int32_t)(lv * T + s) : -1;
         lmax = (int32_t)lv;
     }
-    // one atomic per wave, not per node (4 M atomics on one address: 0.75 ms at config 2)
+    // one atomic per workgroup, and only when it can still raise the maximum (atomics on ONE address serialise in L2 at ~10 ns each:
+    // one per node 0.75 ms at config 2, one per wave 0.70 ms, this ~0.03 ms)
+    __shared__ int s_max[4];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) lmax = max(lmax, __shfl_xor(lmax, m, 64));
-    if ((threadIdx.x & 63) == 0 && lmax > 0) atomicMax(maxlevel, lmax);
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = lmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lmax = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+        if (lmax > __hip_atomic_load(maxlevel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxlevel, lmax);
+    }
 }
 
 // every source of an updated node must sit on a strictly lower level
@@ -435,6 +442,51 @@ __global__ __launch_bounds__(256) void k_seg_level_counts(int64_t G, const int32
     if (g >= G) return;
     const int n = counts[g], s = n > seg ? (n + seg - 1) / seg : 1;
     nseg[g] = s; part[g] = s > 1 ? s : 0; multi[g] = s > 1;
+}
+// the same five steps (counts -> nseg / part / multi, their four exclusive scans, the totals) by ONE workgroup: most levels have a few
+// thousand colours at most, and 14 launches for them cost more than the work
+__global__ __launch_bounds__(1024) void k_seg_level_small(int64_t G, const int32_t* counts, int seg, int32_t* nseg, int32_t* first, int32_t* start,
+                                                          int32_t* pfirst, int32_t* midx, int32_t* totals) {
+    __shared__ int s_w[16][4];
+    __shared__ int s_carry[4];
+    if (threadIdx.x < 4) s_carry[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t g0 = 0; g0 < G; g0 += 1024) {
+        const int64_t g = g0 + threadIdx.x;
+        int v[4] = {0, 0, 0, 0};
+        if (g < G) {
+            const int n = counts[g], s = n > seg ? (n + seg - 1) / seg : 1;
+            nseg[g] = s;
+            v[0] = s; v[1] = n; v[2] = s > 1 ? s : 0; v[3] = s > 1;
+        }
+        int inc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            inc[c] = v[c];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc[c], d, 64); if (lane >= d) inc[c] += u; }
+            if (lane == 63) s_w[w][c] = inc[c];
+        }
+        __syncthreads();
+        int off[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            off[c] = s_carry[c];
+            for (int k = 0; k < w; ++k) off[c] += s_w[k][c];
+        }
+        if (g < G) { first[g] = off[0] + inc[0] - v[0]; start[g] = off[1] + inc[1] - v[1]; pfirst[g] = off[2] + inc[2] - v[2]; midx[g] = off[3] + inc[3] - v[3]; }
+        __syncthreads();
+        if (threadIdx.x == 1023) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_carry[c] = off[c] + inc[c];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        first[G] = s_carry[0]; start[G] = s_carry[1]; pfirst[G] = s_carry[2]; midx[G] = s_carry[3];
+        totals[0] = s_carry[0]; totals[1] = s_carry[1]; totals[2] = s_carry[2]; totals[3] = s_carry[3];
+    }
 }
 __global__ __launch_bounds__(64) void k_seg_level_totals(int64_t G, const int32_t* first, const int32_t* start, const int32_t* pfirst, const int32_t* midx,
                                                          int32_t* totals) {
@@ -754,6 +806,10 @@ extern "C" int mgv_seg_level_scan(int64_t G, const int32_t* counts, int seg, int
     int32_t* nseg = work + 4; int32_t* part = nseg + G; int32_t* multi = part + G;
     int32_t* first = multi + G; int32_t* start = first + G + 1; int32_t* pfirst = start + G + 1; int32_t* midx = pfirst + G + 1;
     int32_t* scan = midx + G + 1;
+    if (G <= 65536) {
+        hipLaunchKernelGGL(k_seg_level_small, dim3(1), dim3(1024), 0, st, G, counts, seg, nseg, first, start, pfirst, midx, work);
+        MGV_LAUNCH_RET();
+    }
     hipLaunchKernelGGL(k_seg_level_counts, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, G, counts, seg, nseg, part, multi);
     int rc = scan_exclusive(G, nseg, first, scan, st);
     if (rc == MGV_OK) rc = scan_exclusive(G, counts, start, scan, st);
