@@ -260,10 +260,14 @@ __global__ __launch_bounds__(kThreads) void k_class_pull_sum(int64_t N, const fl
 // of <= 64 class members (with the neighbour pull of the stage's backward fused), further levels sum the partial rows; every
 // level's segments are cut class by class on the host side (GraphPlan.class_sum_levels), so no float atomics and no order left
 // to chance.  U members' loads are in flight together; the additions keep list order.
+#ifndef MGV_SEG_U
+#define MGV_SEG_U 2          // members of a segment in flight together
+#define MGV_SEG_D 2          // neighbour rows per member in flight together
+#endif
 template <int H>
 __global__ __launch_bounds__(kThreads) void k_seg_sum(int64_t n_seg, const int32_t* seg_ptr, const int32_t* items, const float* direct,
                                                      const float* agg, const int32_t* ptr, const int32_t* idx, const int32_t* out_row, float* out) {
-    constexpr int LPR = H / 4, U = 2, D = 2;
+    constexpr int LPR = H / 4, U = MGV_SEG_U, D = MGV_SEG_D;
     const int lr = threadIdx.x % LPR;
     const int64_t stride = (int64_t)gridDim.x * (kThreads / LPR);
     for (int64_t s = (int64_t)blockIdx.x * (kThreads / LPR) + threadIdx.x / LPR; s < n_seg; s += stride) {

@@ -53,6 +53,10 @@ def main():
         el = time.perf_counter() - t0
         return el / n * 1e3, t_next / n * 1e3, t_step / n * 1e3
 
+    if os.environ.get('HIGH', '0') == '1':          # the step on a high-priority stream (the device offers normal and high only)
+        hp = torch.cuda.Stream(priority=-1)
+        tr._side = torch.cuda.Stream(priority=-1)
+        torch.cuda.set_stream(hp)
     loop(lambda: batch, 3)
     print('resident: %.2f ms/step wall, %.2f ms waiting for the batch, %.2f ms host enqueue' % loop(lambda: batch, steps))
 
