@@ -488,7 +488,7 @@ int mgv_plan_pairs(int64_t N, const int32_t* in_ptr, const uint8_t* xcls, int32_
  * independent).  check: exact comparison of every node with its group's representative rep[cid[i]] — class, previous colour, degree,
  * neighbour-colour multiset; flags[0] = 1 on any difference, flags[1] = nodes with lists beyond 48 entries, left to the caller. */
 int mgv_colour_keys(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const int64_t* f, int64_t fstride,
-                    const uint8_t* xcls, int64_t* key, void* stream);
+                    const uint8_t* xcls, int key_bits, int64_t* key, void* stream);
 int mgv_colour_check(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const uint8_t* xcls, const int32_t* cid,
                      const int32_t* rep, int32_t* flags, void* stream);
 /* a refinement stage's tables on the device (csrc/plan_build.hip, GraphPlan._quotient_dev): what GraphPlan.quotient composes from torch

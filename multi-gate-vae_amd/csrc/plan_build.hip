@@ -358,7 +358,7 @@ static inline int blocks_for(int64_t n, int per = 256, int cap = 256 * 64) { con
 constexpr int kColourCheckMax = 48;
 
 __global__ __launch_bounds__(256) void k_colour_keys(int64_t N, const int32_t* ptr, const int32_t* idx, const int32_t* prev, const int64_t* f, int64_t fstride,
-                                                     const uint8_t* xcls, int64_t* key) {
+                                                     const uint8_t* xcls, int key_bits, int64_t* key) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const int e0 = ptr[i], e1 = ptr[i + 1];
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k_colour_keys(int64_t N, const int32_t* p
     }
     const unsigned long long k = h1 * 0x1E3779B97F4A7C15ull + h2 + (unsigned long long)f[2 * fstride + prev[i]] + (unsigned long long)xcls[i] * 0x632BE59BD9B4E019ull +
                                  (unsigned long long)(e1 - e0) * 0x2545F4914F6CDD1Dull;
-    key[i] = (int64_t)(k >> 1);          // non-negative: torch.unique sorts signed values
+    key[i] = (int64_t)(k >> (64 - key_bits));          // the top key_bits (<= 63: non-negative, torch sorts signed values)
 }
 
 __global__ __launch_bounds__(256) void k_colour_check(int64_t N, const int32_t* ptr, const int32_t* idx, const int32_t* prev, const uint8_t* xcls,
@@ -734,14 +734,15 @@ extern "C" int mgv_plan_pairs(int64_t N, const int32_t* in_ptr, const uint8_t* x
 
 /* Colour refinement of GraphPlan.quotient (ops.StructEncoderFn's quotient stages).  keys: key[i] = 63-bit grouping key of node i from
  * its feature class, previous colour prev[i], degree and the multiset of its neighbours' previous colours (f = int64 [3][fstride]
- * random values per previous colour).  check: flags[0] = 1 if some node differs from its group's representative rep[cid[i]] in class,
+ * random values per previous colour), cut to its top key_bits bits (the radix sort behind it then runs over key_bits: GraphPlan._key_bits
+ * sizes them so that two of the expected colours collide with probability < 2^-20; a collision costs speed, never correctness).  check: flags[0] = 1 if some node differs from its group's representative rep[cid[i]] in class,
  * previous colour, degree or neighbour-colour multiset (exact comparison); flags[1] = number of nodes whose lists are longer than 48
  * entries and were NOT compared (the caller checks those by sorting).  flags must be zeroed by the caller. */
 extern "C" int mgv_colour_keys(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const int64_t* f, int64_t fstride,
-                               const uint8_t* xcls, int64_t* key, void* stream) {
-    MGV_CHECK_ARG(N >= 0 && nbr_ptr && prev && f && xcls && key);
+                               const uint8_t* xcls, int key_bits, int64_t* key, void* stream) {
+    MGV_CHECK_ARG(N >= 0 && nbr_ptr && prev && f && xcls && key && key_bits >= 16 && key_bits <= 63);
     if (N == 0) return MGV_OK;
-    hipLaunchKernelGGL(k_colour_keys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), N, nbr_ptr, nbr_idx, prev, f, fstride, xcls, key);
+    hipLaunchKernelGGL(k_colour_keys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), N, nbr_ptr, nbr_idx, prev, f, fstride, xcls, key_bits, key);
     MGV_LAUNCH_RET();
 }
 extern "C" int mgv_colour_check(int64_t N, const int32_t* nbr_ptr, const int32_t* nbr_idx, const int32_t* prev, const uint8_t* xcls, const int32_t* cid,

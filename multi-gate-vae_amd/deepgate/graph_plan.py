@@ -342,7 +342,7 @@ class GraphPlan:
                     from ._hip import ptr
                     prev32 = prev.to(torch.int32)
                     mix = torch.empty(N, **i64)
-                    _hip.call('mgv_colour_keys', N, ptr(p), ptr(idx), ptr(prev32), ptr(f), Cp + 1, ptr(xcls), ptr(mix))
+                    _hip.call('mgv_colour_keys', N, ptr(p), ptr(idx), ptr(prev32), ptr(f), Cp + 1, ptr(xcls), self._key_bits(Cp), ptr(mix))
                 else:
                     owner = owners.get(rev)
                     if owner is None:
@@ -424,6 +424,12 @@ class GraphPlan:
         lists_same = sorted_col == sorted_col[(pl[:-1][ri[owner]] + k_in_list).clamp_(max=max(owner.numel() - 1, 0))]
         return bool(same.all()) and bool(lists_same.all())
 
+    def _key_bits(self, Cp):
+        """Bits of the grouping key a refinement stage sorts on: enough that two of the colours to expect (at most 1,024 per previous
+        colour, at most N) share a key with probability below 2^-20 — early stages sort 40-odd bits instead of 63."""
+        expect = min(self.N, int(Cp) * 1024)
+        return min(63, max(24, 2 * max(expect, 2).bit_length() + 20))
+
     QUOTIENT_DEVICE = True      # hip plans: a stage's tables by the plan builder's kernels (_quotient_dev); False: the torch composition below
 
     def _sort_by_key_dev(self, keys, n, K):
@@ -499,8 +505,9 @@ class GraphPlan:
             f = torch.randint(1, 1 << 62, (3, Cp + 1), generator=gen, **i64)
             mix, skey = torch.empty(N, **i64), torch.empty(N, **i64)
             by_colour, temp = torch.empty(N, **i32), torch.empty(t_sort, **i32)
-            _hip.call('mgv_colour_keys', N, ptr(p), ptr(idx), ptr(prev32), ptr(f), Cp + 1, ptr(xcls), ptr(mix))
-            _hip.call('mgv_sort_pairs', 8, N, ptr(mix), ptr(skey), ptr(by_colour), 63, ptr(temp), t_sort)
+            bits = self._key_bits(Cp)
+            _hip.call('mgv_colour_keys', N, ptr(p), ptr(idx), ptr(prev32), ptr(f), Cp + 1, ptr(xcls), bits, ptr(mix))
+            _hip.call('mgv_sort_pairs', 8, N, ptr(mix), ptr(skey), ptr(by_colour), bits, ptr(temp), t_sort)
             cid, starts, rep = torch.empty(N, **i32), torch.empty(N + 1, **i32), torch.empty(N, **i32)
             flags = torch.zeros(3, **i32)                       # [grouping refuted, lists too long for the kernel's check, colours]
             scratch = torch.empty(n_grp, **i32)

@@ -234,20 +234,25 @@ def sweep_fast(p, ctype, hs, plan):
     return _SweepFast.apply(hs, plan, names, *[p[k] for k in names])
 
 
-def readout_prob(p, hf, training, bn_state=None, p_drop=0.0, momentum=0.1):
+def readout_prob(p, hf, training, bn_state=None, p_drop=0.0, momentum=0.1, decisions=None):
     """pred_prob (dg_ae_model_aig.py:102-106) over MLP 64-32-32-1 with BatchNorm1d/ReLU/Dropout
-    (mlp.py:27-47).  `bn_state` holds the running statistics (updated in place when training)."""
+    (mlp.py:27-47).  `bn_state` holds the running statistics (updated in place when training).
+    `decisions` (checker aid, not in the reference): {'relu': [mask1, mask2], 'inside': mask} — the piecewise-linear branches another
+    run took (which ReLUs passed, which outputs the clamp left alone), imposed here instead of decided here, so that two runs whose
+    pre-activations differ by rounding are compared on the SAME linear piece."""
     name = 'readout_prob.fc'
     y = hf
-    for lin, bn in ((0, 1), (4, 5)):
+    for blk, (lin, bn) in enumerate(((0, 1), (4, 5))):
         y = linear(p, '%s.%d' % (name, lin), y)
         rm = p['%s.%d.running_mean' % (name, bn)] if bn_state is None else bn_state['%s.%d.running_mean' % (name, bn)]
         rv = p['%s.%d.running_var' % (name, bn)] if bn_state is None else bn_state['%s.%d.running_var' % (name, bn)]
         y = F.batch_norm(y, rm, rv, p['%s.%d.weight' % (name, bn)], p['%s.%d.bias' % (name, bn)],
                          training=training, momentum=momentum, eps=1e-5)
-        y = F.relu(y)
+        y = F.relu(y) if decisions is None else y * decisions['relu'][blk].to(y.dtype)
         y = F.dropout(y, p_drop, training=training)
     y = linear(p, name + '.8', y)
+    if decisions is not None:
+        return torch.where(decisions['inside'], y, torch.clamp(y, min=0.0, max=1.0).detach())
     return torch.clamp(y, min=0.0, max=1.0)
 
 
@@ -284,14 +289,15 @@ def func_loss(hf, tt_pair_index, tt_sim):
 
 
 def run_batch(p, ctype, batch, training=True, bn_state=None, p_drop=0.0, s_rounds=4, t_rounds=4,
-              layernorm=True, num_rounds=1, plan=None, fast=False):
+              layernorm=True, num_rounds=1, plan=None, fast=False, decisions=None):
     """Trainer.run_batch (trainer.py:131-174).  The edge split keeps only its live effect — a
     permutation of the edges, to which the mean over edges is invariant — and never builds the dead
     N x N mask (preprocessing.py:56-69)."""
     hs, hf, s, t = model_forward(p, ctype, batch, s_rounds, t_rounds, layernorm, num_rounds, plan, fast)
     rl, pred_bin, gt_bin = recon_loss(p, hs, batch['edge_index'], batch['neg_edge_index'])
-    prob = readout_prob(p, hf, training, bn_state, p_drop)
-    pl = F.l1_loss(prob, batch['prob'])
+    prob = readout_prob(p, hf, training, bn_state, p_drop, decisions=decisions)
+    # (`decisions`: see readout_prob; 'sign' = the L1 loss's branch per node, imposed)
+    pl = F.l1_loss(prob, batch['prob']) if decisions is None else (decisions['sign'].to(prob.dtype) * (prob - batch['prob'].to(prob.dtype))).mean()
     fl, _ = func_loss(hf, batch['tt_pair_index'], batch['tt_sim'])
     return {'recon_loss': rl, 'pred_bin': pred_bin, 'gt_bin': gt_bin, 'prob_loss': pl, 'func_loss': fl,
             'hs': hs, 'hf': hf, 's': s, 't': t, 'prob': prob}
