@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fresh', action='store_true', help='skip the second timed loop over fresh batches (collate + H2D + plan per step)')
     ap.add_argument('--loader-workers', type=int, default=4)
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='skip the short config 3 / config 5 runs (child processes, after the timed loops) a default 1-GPU run appends as "other_configs"')
     ap.add_argument('--master-port', type=int, default=29541)
     return ap.parse_args()
 
@@ -200,6 +202,26 @@ def roofline_record(summ, table, N, E, H, step_s):
                 roof['simd_issue_share'] = kern['mfma_busy'] + kern['valu_busy']
             roof['mfma_source'] = 'profiles/%s: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), rocprofv3 --pmc' % fname
     return roof, order
+
+
+def other_configs(dev):
+    """{'cfg3': {...}, 'cfg5': {...}}: ms_per_step / value / workload / dominant-kernel roofline of `bench.py --config K` (6 steps, resident
+    batch, per-GPU share of the config), each from a child process; a failure is recorded as such, never hidden."""
+    import torch
+    torch.cuda.empty_cache()
+    res = {}
+    for k in (3, 5):
+        cmd = [sys.executable, os.path.abspath(__file__), '--config', str(k), '--steps', '6', '--warmup', '2', '--no-cpu-baseline', '--no-fresh',
+               '--no-other-configs']
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+            d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+            res['cfg%d' % k] = {'value': d['value'], 'unit': d['unit'], 'ms_per_step': d['ms_per_step'], 'steps': d['steps'], 'nodes_per_s': d['nodes_per_s'],
+                                'workload': d['config']['workload'], 'losses': d['losses'],
+                                'roofline': {kk: d['roofline'].get(kk) for kk in ('kernel', 'launch_ms', 'bound', 'frac', 'achieved', 'peak', 'unit')}}
+        except Exception as exc:         # noqa: BLE001 (reported in the line)
+            res['cfg%d' % k] = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:200])}
+    return res
 
 
 def main():
@@ -411,6 +433,10 @@ def main():
                     l2 = t2.run_batch(deepgate.CircuitBatch.from_arrays(sample, device=dev))     # fixed negatives of the sample
                 return [float(l2[k]) for k in ('recon_loss', 'prob_loss', 'func_loss')]
             out['cpu_baseline'] = cpu_baseline(a.config, H, rounds, seed_sd, hip_losses=hip_losses)
+        if world == 1 and a.config == 2 and a.batch is None and not a.no_other_configs:
+            # BASELINE.json's other single-GPU configurations (parity-test cases, not the metric): a short resident-batch run each, in a
+            # child process after this one's timed loops are over, so that the driver's default run records them too
+            out['other_configs'] = other_configs(dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
