@@ -352,3 +352,56 @@ def test_colour_check_rejects_a_wrong_grouping():
     assert check(*good) == [0, 0]
     assert check([0, 0, 1, 1, 2, 2, 2, 3], [0, 2, 4, 7])[0] == 1   # 6 ({0,0}) merged with 4 ({0,1}): same degree, another multiset
     assert check([0, 0, 0, 1, 2, 2, 3, 4], [0, 3, 4, 6, 7])[0] == 1   # node 2 (previous colour 1) merged with nodes of previous colour 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,K', [(1, 1), (5000, 3), (70000, 152), (300000, 8192), (300000, 40000), (0, 17)])
+def test_device_stable_sort_by_key_equals_torch(n, K):
+    """GraphPlan._sort_by_key_dev (counting sort of the tile builder, or rocPRIM radix sort over the keys' bits with the permutation as
+    int32): the order of torch's stable sort and the members per key, for key ranges on both sides of the switch."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from deepgate.graph_plan import GraphPlan
+    dev = torch.device('cuda:0')
+    plan = GraphPlan(torch.tensor([[0], [1]], device=dev), 2)
+    g = torch.Generator(device=dev)
+    g.manual_seed(n + K)
+    keys = torch.randint(0, K, (n,), generator=g, device=dev, dtype=torch.int32)
+    if n > 10:
+        keys[: n // 3] = keys[0]                         # one long run
+    order, counts = plan._sort_by_key_dev(keys, n, K)
+    ref = torch.sort(keys.long(), stable=True)
+    assert order.dtype == torch.int32 and torch.equal(order.long(), ref.indices)
+    assert torch.equal(counts.long(), torch.bincount(keys.long(), minlength=K))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['small', 'wide', 'deep', 'zeros'])
+def test_device_segment_tables_equal_the_torch_ones(case):
+    """GraphPlan._class_sum_levels_dev against class_sum_levels (the torch composition) from the same members-per-colour counts: every
+    level's segment pointers, output rows and source rows.  'wide': more than 65,536 colours (the multi-kernel scan path); 'deep': a
+    colour with 64^2 < members (three levels); 'zeros': colours nobody carries keep their zero row."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    from deepgate.graph_plan import GraphPlan
+    dev = torch.device('cuda:0')
+    plan = GraphPlan(torch.tensor([[0], [1]], device=dev), 2)
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    if case == 'small':
+        counts = torch.tensor([3, 70, 1, 64, 65, 4096, 4097], device=dev)
+    elif case == 'wide':
+        counts = torch.randint(0, 6, (150000,), generator=g, device=dev)
+        counts[::5000] = 700
+    elif case == 'deep':
+        counts = torch.tensor([5000, 2, 300000, 64 * 64, 64 * 64 + 1], device=dev)
+    else:
+        counts = torch.tensor([0, 0, 5, 0, 129, 0], device=dev)
+    C = int(counts.numel())
+    cid = torch.repeat_interleave(torch.arange(C, device=dev), counts)
+    order = torch.arange(cid.numel(), device=dev)
+    _, ref = plan.class_sum_levels(cid, C, presorted=(order, counts.long()))
+    got = plan._class_sum_levels_dev(counts.to(torch.int32).contiguous(), C)
+    _same_tables(got, ref, case)
+    if case == 'deep':
+        assert len(ref['levels']) >= 3
