@@ -8,6 +8,10 @@
 //   4 WcT_hi 5 WcT_lo 6 WhhT_hi 7 WhhT_lo  ([H][3H], k contiguous: dgrad B operands)
 #include "struct_stage_x3_common.h"
 
+#ifndef MGV_FWD_D
+#define MGV_FWD_D 3            // neighbour slots per row and gather round of the H = 64 forward
+#endif
+
 namespace mgv {
 
 // gate pre-activations of one tile from the split planes; weights streamed from L2
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(kThreadsF, 2) void k_struct_stage_fwd_x3(StageX3Arg
 #if MGV_ABLF & 4
             for (int rr = 0; rr < RPG; ++rr) { acc[rr] = make_float4(0.1f * lr, 0.2f, 0.3f, 0.4f); own[rr] = acc[rr]; deg[rr] = 2.f; cls[rr] = 1; }
 #else
-            tile_rows<H, RPG, false, (H == 64 ? 3 : 4)>(a, base, grp, S::GROUPS, lr, idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).idx, *idx_lds(idx_base, b).dmax(), acc, own, dy, deg, cls);
+            tile_rows<H, RPG, false, (H == 64 ? MGV_FWD_D : 4)>(a, base, grp, S::GROUPS, lr, idx_lds(idx_base, b).ptr, idx_lds(idx_base, b).idx, *idx_lds(idx_base, b).dmax(), acc, own, dy, deg, cls);
 #endif
 #pragma unroll
             for (int rr = 0; rr < RPG; ++rr) {
