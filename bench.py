@@ -44,7 +44,7 @@ def parse_args():
                     help='negative edges drawn on the device every step (as the reference does) or fixed')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fresh', action='store_true', help='skip the second timed loop over fresh batches (collate + H2D + plan per step)')
-    ap.add_argument('--loader-workers', type=int, default=4)
+    ap.add_argument('--loader-workers', type=int, default=8)
     ap.add_argument('--no-other-configs', action='store_true',
                     help='skip the short config 3 / config 5 runs (child processes, after the timed loops) a default 1-GPU run appends as "other_configs"')
     ap.add_argument('--master-port', type=int, default=29541)
