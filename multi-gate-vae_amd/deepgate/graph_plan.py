@@ -341,8 +341,12 @@ class GraphPlan:
                     from . import _hip
                     from ._hip import ptr
                     prev32 = prev.to(torch.int32)
-                    mix = torch.empty(N, **i64)
-                    _hip.call('mgv_colour_keys', N, ptr(p), ptr(idx), ptr(prev32), ptr(f), Cp + 1, ptr(xcls), self._key_bits(Cp), ptr(mix))
+                    pairs = self._stage1_pairs(xcls) if (t_ == 1 and not force) else None
+                    if pairs is not None:
+                        mix = pairs[0].long()            # stage 1 IS the (in-degree, class) grouping: its table id is the key (as _quotient_dev)
+                    else:
+                        mix = torch.empty(N, **i64)
+                        _hip.call('mgv_colour_keys', N, ptr(p), ptr(idx), ptr(prev32), ptr(f), Cp + 1, ptr(xcls), self._key_bits(Cp), ptr(mix))
                 else:
                     owner = owners.get(rev)
                     if owner is None:
@@ -424,6 +428,13 @@ class GraphPlan:
         lists_same = sorted_col == sorted_col[(pl[:-1][ri[owner]] + k_in_list).clamp_(max=max(owner.numel() - 1, 0))]
         return bool(same.all()) and bool(lists_same.all())
 
+    def _stage1_pairs(self, xcls):
+        """The first refinement stage without a sort: every node starts from the same state, so its colour after the first half round
+        is its (in-degree, feature class) pair — the table the plan builder's pair kernels number in one pass (ids ascending in the
+        pair code, every id present).  None when that table does not apply (a degree above 255, or too many pairs)."""
+        first = self._first_stage_classes_hip(xcls, 1 << 15)
+        return first if (first is not None and first is not False) else None
+
     def _key_bits(self, Cp):
         """Bits of the grouping key a refinement stage sorts on: enough that two of the colours to expect (at most 1,024 per previous
         colour, at most N) share a key with probability below 2^-20 — early stages sort 40-odd bits instead of 63."""
@@ -503,6 +514,26 @@ class GraphPlan:
             rev = t_ % 2 == 0
             p, idx = self.csr(rev)
             f = torch.randint(1, 1 << 62, (3, Cp + 1), generator=gen, **i64)
+            pairs = self._stage1_pairs(xcls) if t_ == 1 else None
+            if pairs is not None:
+                # stage 1 = the (in-degree, class) table (exact by construction: no keys, no sort, no check); every list names the one
+                # shared start row
+                cid, C, rptr, _, xrep = pairs
+                if C * self.QUOTIENT_FRACTION > N:
+                    break
+                dr = rptr[1:] - rptr[:-1]
+                n_ent = int(rptr[-1].item())
+                own32 = torch.zeros(C, **i32)
+                ent = torch.zeros(max(n_ent, 1), **i32)
+                row = torch.repeat_interleave(torch.arange(C, **i32), dr.long())
+                if n_ent == 0:
+                    row = torch.zeros(1, **i32)
+                heavy = torch.nonzero(dr > self.HEAVY_ROW).reshape(-1).to(torch.int32)
+                stages.append(self._stage_tables_dev(C, cid, rev, rptr, own32, xrep, ent, row, n_ent, int(heavy.numel()), heavy, Cp))
+                prev32, Cp, last = cid, C, None
+                if C * self.QUOTIENT_GROWTH * self.QUOTIENT_FRACTION > N:
+                    break
+                continue
             mix, skey = torch.empty(N, **i64), torch.empty(N, **i64)
             by_colour, temp = torch.empty(N, **i32), torch.empty(t_sort, **i32)
             bits = self._key_bits(Cp)
@@ -538,21 +569,28 @@ class GraphPlan:
                 ent.zero_()
             heavy = (torch.nonzero((rptr[1:] - rptr[:-1]) > self.HEAVY_ROW).reshape(-1).to(torch.int32) if n_heavy
                      else torch.zeros(0, **i32))
-            own_o, own_counts = self._sort_by_key_dev(own32, C, Cp)
-            ent_o, ent_counts = self._sort_by_key_dev(ent, n_ent, Cp)
-            stages.append(dict(C=C, cid=cid, rev=rev, ptr=rptr, idx=(ent + C) if n_ent else ent, ent_idx=ent,
-                               own=own32.long(), own32=own32, xcls=xrep, heavy=(int(n_heavy), heavy),
-                               own_rows=own_o, own_levels=self._class_sum_levels_dev(own_counts, Cp),
-                               ent_rows=row.index_select(0, ent_o) if n_ent else ent, ent_levels=self._class_sum_levels_dev(ent_counts, Cp)))
+            stages.append(self._stage_tables_dev(C, cid, rev, rptr, own32, xrep, ent, row, n_ent, int(n_heavy), heavy, Cp))
             prev32, Cp = cid, C
             last = (by_colour, starts)
             if C * self.QUOTIENT_GROWTH * self.QUOTIENT_FRACTION > N:
                 break                        # colours multiply per half round: the next one would not qualify
         if stages:
-            by_colour, starts = last
             C = stages[-1]['C']
-            stages[-1]['sum_levels'] = (by_colour, self._class_sum_levels_dev(starts[1:C + 1] - starts[:C], C))
+            if last is None:                 # (the pair-table stage is the last one: its members by colour through the counting sort)
+                by_colour, counts = self._sort_by_key_dev(stages[-1]['cid'], N, C)
+            else:
+                by_colour, counts = last[0], last[1][1:C + 1] - last[1][:C]
+            stages[-1]['sum_levels'] = (by_colour, self._class_sum_levels_dev(counts, C))
         return stages
+
+    def _stage_tables_dev(self, C, cid, rev, rptr, own32, xrep, ent, row, n_ent, n_heavy, heavy, Cp):
+        """A stage's dict from its colours and representatives' lists: the stable sorts by previous colour and the segment tables."""
+        own_o, own_counts = self._sort_by_key_dev(own32, C, Cp)
+        ent_o, ent_counts = self._sort_by_key_dev(ent, n_ent, Cp)
+        return dict(C=C, cid=cid, rev=rev, ptr=rptr, idx=(ent + C) if n_ent else ent, ent_idx=ent,
+                    own=own32.long(), own32=own32, xcls=xrep, heavy=(int(n_heavy), heavy),
+                    own_rows=own_o, own_levels=self._class_sum_levels_dev(own_counts, Cp),
+                    ent_rows=row.index_select(0, ent_o) if n_ent else ent, ent_levels=self._class_sum_levels_dev(ent_counts, Cp))
 
     def assemble_quotient(self, parts, node_off, max_stages):
         """Quotient stages of a BATCH from its graphs' own stages (`parts[g]` = GraphPlan(graph g).quotient(..., force=True), cached by
