@@ -373,7 +373,8 @@ class GraphPlan:
                 n_long = 1
                 if self.hip:
                     flags = torch.zeros(2, dtype=torch.int32, device=dev)
-                    _hip.call('mgv_colour_check', N, ptr(p), ptr(idx), ptr(prev32), ptr(xcls), ptr(inv.to(torch.int32)), ptr(rep.to(torch.int32)), ptr(flags))
+                    inv32, rep32 = inv.to(torch.int32), rep.to(torch.int32)      # (named: a temporary would be freed, and its memory reused, before the launch)
+                    _hip.call('mgv_colour_check', N, ptr(p), ptr(idx), ptr(prev32), ptr(xcls), ptr(inv32), ptr(rep32), ptr(flags))
                     bad, n_long = flags.tolist()
                     if bad:
                         break

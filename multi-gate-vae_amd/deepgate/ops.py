@@ -914,8 +914,9 @@ class EdgeDotFn(torch.autograd.Function):
         sd, td, src, dst = ctx.saved_tensors
         H = sd.shape[1]
         ds, dt = torch.zeros_like(sd), torch.zeros_like(td)
+        gout = gout.contiguous()             # (named: the launcher takes a raw pointer)
         _hip.call('mgv_edge_dot_bwd', H, src.numel(), ptr(sd), ptr(td), H, ptr(src), ptr(dst), int(ctx.sigmoid),
-                  ptr(gout.contiguous()), ptr(ds), ptr(dt))
+                  ptr(gout), ptr(ds), ptr(dt))
         return ds, dt, None, None
 
 
