@@ -130,6 +130,21 @@ int mgv_linear_x3_supported(int M, int K);
 int mgv_wpack_bf16x3(const float* W, int R, int K, int ldw, int transpose, void* hi, void* lo, void* stream);
 int mgv_linear_fwd_x3(int64_t N, const float* X1, int K1, int ld1, const float* X2, int K2, int ld2,
                       const void* wpack_bf16, const float* b, int M, float* Y, int ldy, void* stream);
+/* grouped Linear over the level sweep's tiles (num_rounds > 1, dg_ae_model_aig.py:70,88-94: every updated gate's GRU adds W_hh h_prev + b_hh
+ * with its OWN aggregator's weights — here one launch over all tiles instead of an index_select / Linear / index_copy per gate type).
+ * Row r of tile t is NODE order[tile_start[t] + r] (r < tile_count[t]); X / Y / R / dY rows are indexed by node.  fwd: tile t multiplies by
+ * the pack of slot tile_slot[t] (wpack_bf16[T][2][M*K], fragment order as mgv_wpack_bf16x3 writes it) and adds b[tile_slot[t]][M];
+ * tile_list (nullable) names the tiles to visit (ntiles entries; NULL: tiles 0 .. ntiles-1).  wgrad: dW[M][K] += dY^T X, db[M] += colsum(dY)
+ * over the rows of the listed tiles (ONE slot's list: GraphPlan.slot_tiles).  Shapes at H = 64: (M, K) = (192, 64) and (64, 192) forward,
+ * (192, 64) weight gradient. */
+int mgv_grouped_linear_supported(int M, int K);
+int mgv_grouped_linear_fwd_x3(int64_t ntiles, const int32_t* tile_list, const int32_t* order, const int32_t* tile_start,
+                              const int32_t* tile_count, const int32_t* tile_slot, const float* X, int K, int ldx,
+                              const void* wpack_bf16, const float* b, int M, const float* R, int ldr, float* Y, int ldy, void* stream);
+int mgv_grouped_linear_wgrad_x3_ws_floats(int M, int K, int64_t ntiles);                            /* a size */
+int mgv_grouped_linear_wgrad_x3(int64_t ntiles, const int32_t* tile_list, const int32_t* order, const int32_t* tile_start,
+                                const int32_t* tile_count, const float* X, int K, int ldx, const float* dY, int lddy, int M,
+                                float* dW, float* db, float* workspace, int64_t workspace_floats, void* stream);
 /* the same with residual rows: Y = [X1 | X2] W^T + b + R (R [N][ldr >= M]).  Used as the input gradient of a Linear whose input has a
  * second consumer (hs: hs_decompose and the level sweep, dg_ae_model_aig.py:64-70,109): the other consumer's gradient rides in as R
  * instead of meeting this one in a separate N x M add */

@@ -21,6 +21,23 @@ struct LinX3Args {
     const float* dY; int lddy;
     float* dW; float* db;
     float* slab;            // weight gradient: [gridDim][M*K + M] per-workgroup partials (dW row-major, then db)
+    // grouped mode (order != nullptr): the rows are the level sweep's tiles — row r of tile t is NODE order[tile_start[t] + r]
+    // (r < tile_count[t]); X / Y / R / dY rows are indexed by node; the forward takes tile t's weights from the pack of slot
+    // tile_slot[t] (g_wstride elements apart) and its bias from b + tile_slot[t] * M.  tile_list (nullable) names the tiles.
+    const int32_t* order; const int32_t* tile_start; const int32_t* tile_count; const int32_t* tile_slot; const int32_t* tile_list;
+    int64_t g_ntiles; int64_t g_wstride;
+};
+
+// the wave split of a 64-row tile over M output columns (mgv_common.h WaveSplit without its H <= 128 bound: M = 3H = 192 here)
+template <int M>
+struct LinSplit {
+    static_assert(M % 16 == 0, "column tiles of 16");
+    static constexpr int HC = M / 16;
+    static constexpr int WPC = HC < 4 ? HC : 4;
+    static constexpr int WPR = 4 / WPC;
+    static constexpr int RTW = 4 / WPR;
+    static constexpr int HCW = HC / WPC;
+    static_assert(HCW * WPC == HC, "column tiles must split over the waves");
 };
 
 __device__ __forceinline__ float4 f4x(const f32x4& v) { return make_float4(v[0], v[1], v[2], v[3]); }
@@ -28,7 +45,7 @@ __device__ __forceinline__ float4 f4x(const f32x4& v) { return make_float4(v[0],
 // ---------------------------------------------------------------------------------------------- forward
 template <int M, int K>
 struct LinFwdGeom {
-    using S = WaveSplit<M>;                                   // 4 waves (mgv_common.h)
+    using S = LinSplit<M>;                                    // 4 waves
     static constexpr int KS = K / 32;
     static constexpr int LDP = K + 8;                         // bf16 plane row
     static constexpr int PB = kTileRows * LDP * 2;
@@ -40,7 +57,7 @@ struct LinFwdGeom {
     static_assert(PF * kThreads == F4 && K % 32 == 0, "tile must split over the threads");
 };
 
-template <int M, int K>
+template <int M, int K, bool GROUPED = false>
 __global__ __launch_bounds__(kThreads) void k_linear_fwd_x3(LinX3Args a) {
     using G = LinFwdGeom<M, K>;
     using S = typename G::S;
@@ -50,35 +67,52 @@ __global__ __launch_bounds__(kThreads) void k_linear_fwd_x3(LinX3Args a) {
     float* s_y = reinterpret_cast<float*>(smem_raw + G::o_y);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wc = w % S::WPC, wr = w / S::WPC;
-    // this wave's weight fragments: column tiles wc*HCW.., all k-steps, hi and lo
+    // this wave's weight fragments: column tiles wc*HCW.., all k-steps, hi and lo (grouped mode: reloaded per tile, the tile's slot)
     bf16x8 wh[S::HCW][G::KS], wl[S::HCW][G::KS];
     float bias[S::HCW];
+    constexpr bool grouped = GROUPED;          // (its own instantiation: the plain kernels carry none of this)
+    auto load_weights = [&](const __bf16* wp, const float* bp) {
 #pragma unroll
-    for (int j = 0; j < S::HCW; ++j) {
+        for (int j = 0; j < S::HCW; ++j) {
 #pragma unroll
-        for (int ks = 0; ks < G::KS; ++ks) {
-            const int wo = (((wc * S::HCW + j) * G::KS) + ks) * 512 + lane * 8;
-            wh[j][ks] = ldfrag(a.wpack + wo); wl[j][ks] = ldfrag(a.wpack + M * K + wo);
+            for (int ks = 0; ks < G::KS; ++ks) {
+                const int wo = (((wc * S::HCW + j) * G::KS) + ks) * 512 + lane * 8;
+                wh[j][ks] = ldfrag(wp + wo); wl[j][ks] = ldfrag(wp + M * K + wo);
+            }
+            bias[j] = bp ? bp[(wc * S::HCW + j) * 16 + r] : 0.f;
         }
-        bias[j] = a.b ? a.b[(wc * S::HCW + j) * 16 + r] : 0.f;
-    }
-    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+    };
+    if (!grouped) load_weights(a.wpack, a.b);
+    const int64_t ntiles = grouped ? a.g_ntiles : (a.N + kTileRows - 1) / kTileRows;
+    // rows of a tile -> node ids: plain tiles are 64 consecutive nodes; grouped tiles go through the sweep's order list
+    auto tile_span = [&](int64_t tile, int64_t& first, int& cnt, int& slot) {
+        if (grouped) {
+            const int64_t t = a.tile_list ? (int64_t)a.tile_list[tile] : tile;
+            first = a.tile_start[t]; cnt = a.tile_count[t]; slot = a.tile_slot ? a.tile_slot[t] : 0;
+        } else {
+            first = tile * kTileRows; cnt = (int)(a.N - first < kTileRows ? a.N - first : kTileRows); slot = 0;
+        }
+    };
+    auto node_of = [&](int64_t first, int cnt, int row) -> int64_t { return row < cnt ? (grouped ? (int64_t)a.order[first + row] : first + row) : -1; };
     f32x4 pf[G::PF];
     auto prefetch = [&](int64_t tile) {
-        const int64_t base = tile * kTileRows;
+        int64_t first; int cnt, slot;
+        tile_span(tile, first, cnt, slot);
 #pragma unroll
         for (int u = 0; u < G::PF; ++u) {
             const int f = tid + u * kThreads;
             const int row = f / (K / 4), c4 = (f % (K / 4)) * 4;
-            const int64_t node = base + row;
-            if (node < a.N) pf[u] = *reinterpret_cast<const f32x4*>(c4 < a.K1 ? a.X1 + node * a.ld1 + c4 : a.X2 + node * a.ld2 + (c4 - a.K1));
+            const int64_t node = node_of(first, cnt, row);
+            if (node >= 0) pf[u] = *reinterpret_cast<const f32x4*>(c4 < a.K1 ? a.X1 + node * a.ld1 + c4 : a.X2 + node * a.ld2 + (c4 - a.K1));
             else pf[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     int64_t tile = blockIdx.x;
     if (tile < ntiles) prefetch(tile);
     for (; tile < ntiles; tile += gridDim.x) {
-        const int64_t base = tile * kTileRows;
+        int64_t first; int cnt, slot;
+        tile_span(tile, first, cnt, slot);
+        if (grouped) load_weights(a.wpack + (int64_t)slot * a.g_wstride, a.b ? a.b + (int64_t)slot * M : nullptr);
 #pragma unroll
         for (int u = 0; u < G::PF; ++u) {
             const int f = tid + u * kThreads;
@@ -114,8 +148,8 @@ __global__ __launch_bounds__(kThreads) void k_linear_fwd_x3(LinX3Args a) {
         lds_barrier();
         for (int i = tid; i < kTileRows * (M / 4); i += kThreads) {
             const int row = i / (M / 4), c4 = (i % (M / 4)) * 4;
-            const int64_t node = base + row;
-            if (node < a.N) {
+            const int64_t node = node_of(first, cnt, row);
+            if (node >= 0) {
                 float4 v = ld4(s_y + row * G::LDY + c4);
                 if (a.R) v = add4(v, ld4(a.R + node * a.ldr + c4));
                 st4(a.Y + node * a.ldy + c4, v);
@@ -142,7 +176,7 @@ struct LinWgGeom {
     static constexpr int smem_bytes = o_db + M * 4;
 };
 
-template <int M, int K, int NW, int WI>
+template <int M, int K, int NW, int WI, bool GROUPED = false>
 __global__ __launch_bounds__(64 * NW) void k_linear_wgrad_x3(LinX3Args a) {
     using G = LinWgGeom<M, K, NW, WI>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -161,23 +195,29 @@ __global__ __launch_bounds__(64 * NW) void k_linear_wgrad_x3(LinX3Args a) {
         for (int j = 0; j < G::JTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float4 dbs = zero4();            // column sums of dY over this thread's rows (its column quad is fixed)
     f32x4 pg[G::PFG], px[G::PFX];
-    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+    constexpr bool grouped = GROUPED;
+    const int64_t ntiles = grouped ? a.g_ntiles : (a.N + kTileRows - 1) / kTileRows;
     auto prefetch = [&](int64_t tile) {
-        const int64_t base = tile * kTileRows;
+        int64_t first = tile * kTileRows;
+        int cnt = (int)(a.N - first < kTileRows ? a.N - first : kTileRows);
+        if (grouped) {
+            const int64_t t = a.tile_list ? (int64_t)a.tile_list[tile] : tile;
+            first = a.tile_start[t]; cnt = a.tile_count[t];
+        }
 #pragma unroll
         for (int u = 0; u < G::PFG; ++u) {
             const int f = tid + u * G::NT;
             const int row = f / (M / 4), c4 = (f % (M / 4)) * 4;
-            const int64_t node = base + row;
-            if (f < G::F4G && node < a.N) pg[u] = *reinterpret_cast<const f32x4*>(a.dY + node * a.lddy + c4);
+            const int64_t node = row < cnt ? (grouped ? (int64_t)a.order[first + row] : first + row) : -1;
+            if (f < G::F4G && node >= 0) pg[u] = *reinterpret_cast<const f32x4*>(a.dY + node * a.lddy + c4);
             else pg[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int u = 0; u < G::PFX; ++u) {
             const int f = tid + u * G::NT;
             const int row = f / (K / 4), c4 = (f % (K / 4)) * 4;
-            const int64_t node = base + row;
-            if (f < G::F4X && node < a.N) px[u] = *reinterpret_cast<const f32x4*>(c4 < a.K1 ? a.X1 + node * a.ld1 + c4 : a.X2 + node * a.ld2 + (c4 - a.K1));
+            const int64_t node = row < cnt ? (grouped ? (int64_t)a.order[first + row] : first + row) : -1;
+            if (f < G::F4X && node >= 0) px[u] = *reinterpret_cast<const f32x4*>(c4 < a.K1 ? a.X1 + node * a.ld1 + c4 : a.X2 + node * a.ld2 + (c4 - a.K1));
             else px[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
@@ -264,30 +304,30 @@ __global__ __launch_bounds__(256) void k_wpack_bf16x3(const float* W, int R, int
     }
 }
 
-template <int M, int K>
+template <int M, int K, bool GROUPED = false>
 int launch_linear_fwd_x3(const LinX3Args& a, hipStream_t st) {
     using G = LinFwdGeom<M, K>;
     static bool set = false;
-    if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_fwd_x3<M, K>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+    if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_fwd_x3<M, K, GROUPED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    const int64_t ntiles = a.order ? a.g_ntiles : (a.N + kTileRows - 1) / kTileRows;
     int per_cu = 160 * 1024 / G::smem_bytes;
     per_cu = per_cu > 4 ? 4 : per_cu;
-    hipLaunchKernelGGL((k_linear_fwd_x3<M, K>), dim3(grid_for(ntiles, per_cu)), dim3(kThreads), G::smem_bytes, st, a);
+    hipLaunchKernelGGL((k_linear_fwd_x3<M, K, GROUPED>), dim3(grid_for(ntiles, per_cu)), dim3(kThreads), G::smem_bytes, st, a);
     MGV_LAUNCH_RET();
 }
 
-template <int M, int K, int NW, int WI>
+template <int M, int K, int NW, int WI, bool GROUPED = false>
 int launch_linear_wgrad_x3(const LinX3Args& a, int64_t ws_floats, hipStream_t st) {
     using G = LinWgGeom<M, K, NW, WI>;
     static bool set = false;
-    if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_wgrad_x3<M, K, NW, WI>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
-    const int64_t ntiles = (a.N + kTileRows - 1) / kTileRows;
+    if (!set) { hipFuncSetAttribute(reinterpret_cast<const void*>(k_linear_wgrad_x3<M, K, NW, WI, GROUPED>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set = true; }
+    const int64_t ntiles = a.order ? a.g_ntiles : (a.N + kTileRows - 1) / kTileRows;
     int per_cu = 160 * 1024 / G::smem_bytes;
     const int cap = 1024 / G::NT;                    // 16 waves per CU
     per_cu = per_cu > cap ? cap : per_cu;
     const int grid = grid_for(ntiles, per_cu);
     if (a.slab == nullptr || ws_floats < (int64_t)grid * (M * K + M)) return MGV_EINVAL;
-    hipLaunchKernelGGL((k_linear_wgrad_x3<M, K, NW, WI>), dim3(grid), dim3(G::NT), G::smem_bytes, st, a);
+    hipLaunchKernelGGL((k_linear_wgrad_x3<M, K, NW, WI, GROUPED>), dim3(grid), dim3(G::NT), G::smem_bytes, st, a);
     launch_slab_sum<float, float>(a.slab, grid, M * K + M, M * K, a.dW, st);
     if (a.db) launch_slab_sum<float, float>(a.slab + M * K, grid, M * K + M, M, a.db, st);
     MGV_LAUNCH_RET();
@@ -358,4 +398,43 @@ extern "C" int mgv_wpack_bf16x3(const float* W, int R, int K, int ldw, int trans
     hipLaunchKernelGGL(mgv::k_wpack_bf16x3, dim3((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256), dim3(256), 0,
                        static_cast<hipStream_t>(stream), W, R, K, ldw, transpose, static_cast<__bf16*>(hi), static_cast<__bf16*>(lo));
     MGV_LAUNCH_RET();
+}
+
+/* ---- grouped Linear over the level sweep's tiles (num_rounds > 1: gh = W_hh[slot] h_prev + b_hh[slot] per updated gate with its OWN
+ * aggregator's GRU weights, dg_ae_model_aig.py:88-94; one launch instead of an index_select / three Linears / index_copy per gate type).
+ * H = 64 shapes: (M, K) = (192, 64) forward, (64, 192) input gradient, (192, 64) weight gradient of ONE slot's tile list. */
+extern "C" int mgv_grouped_linear_supported(int M, int K) { return (M == 192 && K == 64) || (M == 64 && K == 192); }
+
+extern "C" int mgv_grouped_linear_fwd_x3(int64_t ntiles, const int32_t* tile_list, const int32_t* order, const int32_t* tile_start,
+                                         const int32_t* tile_count, const int32_t* tile_slot, const float* X, int K, int ldx,
+                                         const void* wpack_bf16, const float* b, int M, const float* R, int ldr, float* Y, int ldy, void* stream) {
+    MGV_CHECK_ARG(ntiles >= 0 && order && tile_start && tile_count && tile_slot && X && wpack_bf16 && Y);
+    MGV_CHECK_ARG(K % 4 == 0 && ldx >= K && ldx % 4 == 0 && ldy >= M && ldy % 4 == 0 && (R == nullptr || (ldr >= M && ldr % 4 == 0)));
+    if (ntiles == 0) return MGV_OK;
+    mgv::LinX3Args a{};
+    a.N = 0; a.X1 = X; a.K1 = K; a.ld1 = ldx; a.wpack = static_cast<const __bf16*>(wpack_bf16); a.b = b; a.Y = Y; a.ldy = ldy; a.R = R; a.ldr = ldr;
+    a.order = order; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_slot = tile_slot; a.tile_list = tile_list;
+    a.g_ntiles = ntiles; a.g_wstride = (int64_t)2 * M * K;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (M == 192 && K == 64) return mgv::launch_linear_fwd_x3<192, 64, true>(a, st);
+    if (M == 64 && K == 192) return mgv::launch_linear_fwd_x3<64, 192, true>(a, st);
+    return MGV_EUNSUPPORTED;
+}
+
+extern "C" int mgv_grouped_linear_wgrad_x3_ws_floats(int M, int K, int64_t ntiles) {
+    if (M <= 0 || K <= 0 || ntiles < 0) return 0;
+    return mgv::grid_for(ntiles, 4) * (M * K + M);
+}
+
+extern "C" int mgv_grouped_linear_wgrad_x3(int64_t ntiles, const int32_t* tile_list, const int32_t* order, const int32_t* tile_start,
+                                           const int32_t* tile_count, const float* X, int K, int ldx, const float* dY, int lddy, int M,
+                                           float* dW, float* db, float* workspace, int64_t workspace_floats, void* stream) {
+    MGV_CHECK_ARG(ntiles >= 0 && order && tile_start && tile_count && X && dY && dW && K % 4 == 0 && ldx % 4 == 0 && lddy % 4 == 0 && lddy >= M);
+    if (ntiles == 0) return MGV_OK;
+    mgv::LinX3Args a{};
+    a.N = 0; a.X1 = X; a.K1 = K; a.ld1 = ldx; a.dY = dY; a.lddy = lddy; a.dW = dW; a.db = db; a.slab = workspace;
+    a.order = order; a.tile_start = tile_start; a.tile_count = tile_count; a.tile_list = tile_list; a.g_ntiles = ntiles;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (M == 192 && K == 64) return mgv::launch_linear_wgrad_x3<192, 64, 6, 3, true>(a, workspace_floats, st);
+    return MGV_EUNSUPPORTED;
 }

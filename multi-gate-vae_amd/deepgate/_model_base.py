@@ -80,9 +80,14 @@ class FunctionalModel(nn.Module):
         return hs, hf
 
     def _round_gh(self, plan, hf):
-        """gh[N, 3H] = W_hh h_prev + b_hh with each updated node's OWN aggregator weights (nn.GRU gate order r, z, n), on the linear
-        kernels: the rows of every gate type are gathered, multiplied per gate block and put back (index moves only)."""
+        """gh[N, 3H] = W_hh h_prev + b_hh with each updated node's OWN aggregator weights (nn.GRU gate order r, z, n): at H = 64 in bf16x3
+        mode one grouped Linear launch over the sweep's tiles; otherwise on the plain linear kernels: the rows of every gate type are
+        gathered, multiplied per gate block and put back (index moves only)."""
         H = self.dim_hidden
+        if hf.is_cuda and H == 64 and ops.use_x3(H) and ops.GROUPED_ROUND:
+            # one grouped Linear over the sweep's (level, slot) tiles, each tile with its slot's weights (ops.RoundGhFn)
+            grus = [getattr(self, 'update_%s_func' % name) for name, _ in self.GATES]
+            return ops.RoundGhFn.apply(plan, hf, torch.stack([g.weight_hh_l0 for g in grus]), torch.stack([g.bias_hh_l0 for g in grus]))
         gh = torch.zeros(hf.shape[0], 3 * H, dtype=hf.dtype, device=hf.device)
         for (name, _), idx in zip(self.GATES, plan.slot_nodes()):
             if idx.numel() == 0:

@@ -570,6 +570,54 @@ def linear_passthrough(x, W, b=None):
     return LinearFn.apply(x, None, W, b, True)
 
 
+class RoundGhFn(torch.autograd.Function):
+    """gh[N, 3H] = W_hh[slot(v)] h[v] + b_hh[slot(v)] for every node v the sweep updates (zero rows elsewhere): the hidden half of each
+    gate's own GRU for rounds >= 2 (dg_ae_model_aig.py:70,88-94), as ONE grouped Linear over the sweep's (level, slot) tiles
+    (csrc/linear_x3.hip grouped mode) — and its backward: the input gradient as a grouped Linear with the transposed packs, the weight
+    and bias gradients per slot over the slot's tile list.  W [T, 3H, H], b [T, 3H] stacked in slot order."""
+
+    @staticmethod
+    def forward(ctx, plan, h, W, b):
+        hd, Wd, bd = check(h.detach().contiguous(), F32, 'h'), check(W.detach().contiguous(), F32, 'W'), check(b.detach().contiguous(), F32, 'b')
+        N, H = hd.shape
+        T, M = Wd.shape[0], 3 * H
+        assert plan.has_levels and plan.num_slots == T and plan.N == N and Wd.shape == (T, M, H) and bd.shape == (T, M)
+        pack = torch.empty(T, 2, M * H, dtype=torch.bfloat16, device=hd.device)
+        for s_ in range(T):
+            _hip.call('mgv_wpack_bf16x3', ptr(Wd[s_]), M, H, H, 0, ptr(pack[s_, 0]), ptr(pack[s_, 1]))
+        gh = torch.zeros(N, M, dtype=F32, device=hd.device)
+        _hip.call('mgv_grouped_linear_fwd_x3', plan.num_tiles, None, ptr(plan.order), ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot),
+                  ptr(hd), H, H, ptr(pack), ptr(bd), M, None, 0, ptr(gh), M)
+        ctx.save_for_backward(hd, Wd)
+        ctx.plan = plan
+        return gh
+
+    @staticmethod
+    def backward(ctx, dgh):
+        hd, Wd = ctx.saved_tensors
+        plan = ctx.plan
+        d = check(dgh.contiguous(), F32, 'dgh')
+        N, H = hd.shape
+        T, M = Wd.shape[0], 3 * H
+        packT = torch.empty(T, 2, H * M, dtype=torch.bfloat16, device=hd.device)
+        for s_ in range(T):
+            _hip.call('mgv_wpack_bf16x3', ptr(Wd[s_]), H, M, H, 1, ptr(packT[s_, 0]), ptr(packT[s_, 1]))      # the transposed view of W[s]
+        dh = torch.zeros(N, H, dtype=F32, device=hd.device)
+        _hip.call('mgv_grouped_linear_fwd_x3', plan.num_tiles, None, ptr(plan.order), ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot),
+                  ptr(d), M, M, ptr(packT), None, H, None, 0, ptr(dh), H)
+        dW, db = torch.zeros_like(Wd), torch.zeros(T, M, dtype=F32, device=hd.device)
+        stp = plan.slot_tile_ptr
+        for s_ in range(T):
+            n_t = stp[s_ + 1] - stp[s_]
+            if n_t == 0:
+                continue
+            ws = workspace(_hip.call_value('mgv_grouped_linear_wgrad_x3_ws_floats', M, H, n_t), hd.device)
+            tiles = plan.slot_tiles[stp[s_]:]
+            _hip.call('mgv_grouped_linear_wgrad_x3', n_t, ptr(tiles), ptr(plan.order), ptr(plan.tile_start), ptr(plan.tile_count), ptr(hd), H, H,
+                      ptr(d), M, M, ptr(dW[s_]), ptr(db[s_]), ptr(ws), ws.numel())
+        return None, dh, dW, db
+
+
 class GatherSumFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, plan, reverse):
@@ -670,6 +718,8 @@ def _sweep_x3(H):
 # grid barrier, in-register weight gradient).  Built, parity-tested and MEASURED in round 4: not faster than the per-level kernels at any
 # batch size (config 2: forward 2.17 vs 2.00 ms, backward 8.2 vs 7.4 ms; one graph: 0.95 / 2.80 vs 1.01 / 2.84 ms), so it is
 # opt-in (MGV_SWEEP_PERSIST=1) and the per-level kernels stay the default.
+GROUPED_ROUND = True            # rounds >= 2: W_hh h_prev + b_hh of every updated gate as one grouped Linear (RoundGhFn); False: per gate type on the plain kernels
+
 # the level kernels read packed rows (GraphPlan.order_rows: spans + first in-edge sources + first consumers, one 128-byte line per
 # updated node) unless MGV_PACKED_ROWS=0 (then the 16-byte span rows and the CSR lists behind them)
 PACKED_ROWS = os.environ.get('MGV_PACKED_ROWS', '1') != '0'

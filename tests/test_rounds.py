@@ -197,3 +197,47 @@ def test_standalone_aggregator_on_hip_against_the_oracle(H, N, E):
         if k == 'attn_lin.weight':
             g_, r_ = g_[:, H:], r_[:, H:]
         close(g_, r_, rtol=1e-3, atol=1e-4, msg='grad ' + k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('ctype,T', [('xmg', 5), ('aig', 2)])
+def test_grouped_round_linear_against_float64(ctype, T):
+    """ops.RoundGhFn (csrc/linear_x3.hip grouped mode: W_hh[slot] h + b_hh[slot] for every updated gate in one launch over the sweep's
+    tiles, partial tiles included; rounds >= 2 of dg_ae_model_aig.py:70,88-94) against float64 torch per gate type: gh, zero rows for the
+    nodes no aggregator updates, and the gradients of h, W and b (bf16x3: 2e-4 of scale)."""
+    if not torch.cuda.is_available():
+        pytest.skip('needs a GPU')
+    import deepgate
+    from deepgate import ops, synthetic as syn
+    if ops.PRECISION != 'x3':
+        pytest.skip('bf16x3 mode only')
+    dev = torch.device('cuda:0')
+    H = 64
+    g = [syn.make_graph(ctype, 150 + 37 * 45, 37, 11 + i, n_inputs=150) for i in range(2)]       # 45 nodes per level: partial tiles
+    a = syn.collate(g)
+    batch = deepgate.CircuitBatch.from_arrays(a, device=dev)
+    gates = [gid for _, gid in getattr(deepgate, 'dg_ae_model_' + ctype).Model.GATES]
+    assert len(gates) == T
+    plan = deepgate.data.plan_of(batch, gates)
+    N = plan.N
+    torch.manual_seed(3 + T)
+    h = torch.randn(N, H, device=dev, requires_grad=True)
+    W = (torch.randn(T, 3 * H, H, device=dev) * 0.2).requires_grad_(True)
+    b = (torch.randn(T, 3 * H, device=dev) * 0.1).requires_grad_(True)
+    gout = torch.randn(N, 3 * H, device=dev)
+    gh = ops.RoundGhFn.apply(plan, h, W, b)
+    (gh * gout).sum().backward()
+    h64, W64, b64 = (t.detach().double().cpu().requires_grad_(True) for t in (h, W, b))
+    slot = plan.gslot.cpu().long()
+    ref = torch.zeros(N, 3 * H, dtype=torch.float64)
+    for s_ in range(T):
+        idx = torch.nonzero(slot == s_).reshape(-1)
+        ref = ref.index_add(0, idx, h64[idx] @ W64[s_].t() + b64[s_])
+    (ref * gout.double().cpu()).sum().backward()
+    idle = slot == 255
+    assert int(idle.sum()) > 0 and float(gh.detach().cpu()[idle].abs().max()) == 0.0
+    for name, got, want in (('gh', gh, ref), ('d h', h.grad, h64.grad), ('d W', W.grad, W64.grad), ('d b', b.grad, b64.grad)):
+        want = want.detach()
+        scale = float(want.abs().max())
+        err = float((got.detach().cpu().double() - want).abs().max())
+        assert scale > 0 and err <= 2e-4 * scale, (name, err, scale)
