@@ -175,10 +175,18 @@ class GraphPlan:
             hit = cache[reverse] = (class_id, (idx | (class_id[idx.long()] << 24)).to(torch.int32).contiguous())
         return hit[1]
 
+    def count_self_loops(self):
+        """Edges (v, v): the negative sampler draws E - self loops + N pairs (sampling.negative_sampling_device).  One host read-back,
+        kept on the plan."""
+        if getattr(self, 'num_self_loops', None) is None:
+            self.num_self_loops = int((self.in_src == self.in_dst).sum().item()) if self.E > 0 else 0
+        return self.num_self_loops
+
     def warm(self, xcls=None, quotient_stages=0):
         """Build, on the CURRENT stream, the per-batch caches a train step would otherwise build lazily inside the step (each with a
         host read-back): the first-stage (degree, class) table and the tagged lists of the half round after it, the heavy-row lists
         and their segments.  The batch prefetcher calls this on its worker's stream, beside the previous step."""
+        self.count_self_loops()
         for rev in (False, True):
             self.heavy(rev)
             self.heavy_segments(rev)

@@ -56,9 +56,7 @@ def negative_sampling_device(plan, num_neg_samples=None, generator=None):
     drawn by one kernel from a counter-based generator seeded from torch's seed and a call counter (no host sync)."""
     N, dev = plan.N, plan.device
     if getattr(plan, 'num_self_loops', None) is None:
-        dst_of = plan.out_dst.long()
-        src_of = torch.repeat_interleave(torch.arange(N, device=dev), (plan.out_ptr[1:] - plan.out_ptr[:-1]).long())
-        plan.num_self_loops = int((dst_of == src_of).sum().item())
+        plan.count_self_loops()              # (one host read-back per plan; GraphPlan.warm does it on the prefetcher's stream for fresh batches)
     E = (plan.E - plan.num_self_loops) + N if num_neg_samples is None else int(num_neg_samples)
     base = generator.initial_seed() if generator is not None else torch.initial_seed()
     seed = (base * 0x9E3779B97F4A7C15 + next(_CALLS) * 0xD1B54A32D192ED03 + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF
