@@ -332,7 +332,10 @@ def main():
     if not a.no_fresh:
         from deepgate.prefetch import BatchPrefetcher, _Staging, collate_into
         skip = ('neg_edge_index',) if a.neg == 'sampled' else ()
-        n_fresh = a.warmup + a.steps
+        # a SUSTAINED rate: enough untimed steps to drain what the prefetcher queued while nothing consumed, enough timed ones to average
+        # over its bursts (the first ~10 steps after a warm-up run 2 % faster than the loop's steady state)
+        f_warm, f_steps = max(a.warmup, 12), max(a.steps, 40)
+        n_fresh = f_warm + f_steps
 
         def chunks():
             for s_ in range(n_fresh):
@@ -345,11 +348,11 @@ def main():
         del host
         pf = BatchPrefetcher(chunks(), dev, gate_ids=gate_ids, workers=a.loader_workers, skip=skip)
         it = iter(pf)
-        for _ in range(a.warmup):
+        for _ in range(f_warm):
             tr.enqueue_metrics(tr.train_step(next(it)))
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(a.steps):
+        for _ in range(f_steps):
             tr.enqueue_metrics(tr.train_step(next(it)))
         tr.flush_metrics()
         sync_all()
@@ -359,7 +362,7 @@ def main():
             tmax = torch.tensor([el_f], dtype=torch.float64, device=dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el_f = float(tmax.item())
-        fresh = {'value': world * B * a.steps / el_f, 'ms_per_step': el_f / a.steps * 1e3, 'loader_workers': a.loader_workers,
+        fresh = {'value': world * B * f_steps / el_f, 'ms_per_step': el_f / f_steps * 1e3, 'steps': f_steps, 'warmup': f_warm, 'loader_workers': a.loader_workers,
                  'h2d_bytes_per_batch': h2d_bytes, 'host_collate_ms_one_thread': collate_ms,
                  'note': 'graphs/s over batches that are collated (pinned staging), copied host-to-device and planned per step on %d worker '
                          'threads with their own HIP streams, overlapped with the previous step; PCIe-inclusive' % a.loader_workers}
