@@ -76,10 +76,36 @@ __global__ __launch_bounds__(256) void k_scan_add(int64_t n, int32_t* out, const
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[nb];       // total behind the last element
 }
 
+// short inputs (most scans of the plan builder: per-colour tables, tile counts): ONE workgroup, one launch instead of three
+__global__ __launch_bounds__(1024) void k_scan_small(int64_t n, const int32_t* in, int32_t* out) {
+    __shared__ int s_w[16];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t b0 = 0; b0 < n; b0 += 1024) {
+        const int64_t i = b0 + threadIdx.x;
+        const int t = i < n ? in[i] : 0;
+        int inc = t;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d, 64); if (lane >= d) inc += u; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int woff = s_carry;
+        for (int k = 0; k < w; ++k) woff += s_w[k];
+        if (i < n) out[i] = woff + inc - t;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = s_carry;
+}
+
 // out[0..n] = exclusive prefix sums of in[0..n), out[n] = total; scratch >= ceil(n / 2048) + 1 ints
 static int scan_exclusive(int64_t n, const int32_t* in, int32_t* out, int32_t* scratch, hipStream_t st) {
     const int nb = (int)((n + kScanItems - 1) / kScanItems);
     if (n == 0) { hipMemsetAsync(out, 0, sizeof(int32_t), st); MGV_LAUNCH_RET(); }
+    if (n <= 32768 && in != out) { hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, n, in, out); MGV_LAUNCH_RET(); }
     hipLaunchKernelGGL(k_scan_block, dim3(nb), dim3(256), 0, st, n, in, out, scratch);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, nb, scratch);
     hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, st, n, out, scratch, nb);
