@@ -582,3 +582,17 @@ def test_batch_quotient_merged_through_the_dataset_wide_colour_dictionary():
         col = [ids[kk] for kk in keys]
     order, levels = q[-1]['sum_levels']
     assert _run_seg_tables(levels, [1] * N)[:q[-1]['C']] == torch.bincount(q[-1]['cid'].long(), minlength=q[-1]['C']).tolist()
+
+
+def test_self_loop_count_and_key_bits():
+    """GraphPlan.count_self_loops (what the device negative sampler subtracts from its draw count; cached on the plan so that a fresh
+    batch's first step does not read it back in the middle of the step) and GraphPlan._key_bits (bits of the grouping key a colour
+    refinement stage sorts on: at least 24, at most 63, growing with the colours to expect, never below what N nodes need)."""
+    ei = torch.tensor([[0, 1, 2, 2, 3, 4, 4], [1, 1, 2, 3, 3, 0, 4]])          # self loops: (1,1), (2,2), (3,3), (4,4)
+    plan = GraphPlan(ei, 6)
+    assert plan.count_self_loops() == 4 and plan.num_self_loops == 4
+    assert GraphPlan(torch.zeros(2, 0, dtype=torch.long), 3).count_self_loops() == 0
+    big = GraphPlan(torch.tensor([[0], [1]]), 1 << 22)
+    bits = [big._key_bits(c) for c in (1, 3, 152, 34377, 1 << 21)]
+    assert bits == sorted(bits) and bits[0] >= 24 and bits[-1] == 63 and bits[0] < 48
+    assert GraphPlan(torch.tensor([[0], [1]]), 100)._key_bits(1 << 20) == 24 + 10      # few nodes: never more colours than nodes (2 * 7 bits + 20)
