@@ -80,11 +80,20 @@ def load():
     return lib
 
 
+class _TensorPtr(ctypes.c_void_p):
+    """A device pointer that keeps its tensor alive for as long as the pointer object lives — i.e. through the launcher call it is an
+    argument of.  `ptr(x.to(torch.int32))` would otherwise free the temporary the moment ptr() returns, and a second temporary in the
+    same argument list could be handed the same memory before the launch (it happened: the colour check of round 4)."""
+    _keep = None
+
+
 def ptr(t):
     """Device pointer of a tensor (None -> NULL)."""
     if t is None:
         return None
-    return ctypes.c_void_p(t.data_ptr())
+    p = _TensorPtr(t.data_ptr())
+    p._keep = t
+    return p
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
