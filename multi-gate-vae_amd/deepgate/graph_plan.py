@@ -194,8 +194,8 @@ class GraphPlan:
             self.heavy_segments(True, inactive_only=True)
             self.heavy_segments(True, active_by_level=True)
         from . import ops
-        if self.has_levels and ops.PACKED_ROWS:
-            self.order_rows
+        if self.has_levels and ops.PACKED_ROWS == 2:
+            self.order_rows                  # (default: a plan builds its packed sweep rows when it comes back for a second step, ops._sweep_rows)
         counts = sorted({int(c) for c in (quotient_stages if isinstance(quotient_stages, (tuple, list, set)) else [quotient_stages]) if int(c) > 0})
         if xcls is not None and self.N > 0 and counts and ops.QUOTIENT:
             if all([len(self.quotient(xcls, c)) > 0 for c in counts]):
@@ -844,6 +844,7 @@ class GraphPlan:
         self.__dict__.pop('_slot_nodes', None)
         self.__dict__.pop('_persist_roles', None)
         self.__dict__.pop('_order_rows', None)
+        self.__dict__.pop('_sweep_steps', None)
 
     def _set_levels_hip(self, gate, forward_level, gate_ids):
         from . import _hip

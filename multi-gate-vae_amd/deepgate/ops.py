@@ -720,13 +720,22 @@ def _sweep_x3(H):
 # opt-in (MGV_SWEEP_PERSIST=1) and the per-level kernels stay the default.
 GROUPED_ROUND = True            # rounds >= 2: W_hh h_prev + b_hh of every updated gate as one grouped Linear (RoundGhFn); False: per gate type on the plain kernels
 
-# the level kernels read packed rows (GraphPlan.order_rows: spans + first in-edge sources + first consumers, one 128-byte line per
-# updated node) unless MGV_PACKED_ROWS=0 (then the 16-byte span rows and the CSR lists behind them)
-PACKED_ROWS = os.environ.get('MGV_PACKED_ROWS', '1') != '0'
+# The level kernels read packed rows (GraphPlan.order_rows: spans + first in-edge sources + first consumers, one 128-byte line per
+# updated node) or the 16-byte span rows and the CSR lists behind them.  Packed rows cost 0.43 ms to build and save 0.13 ms per sweep
+# backward (config 2): they pay from a plan's THIRD step on, so a plan gets them when it comes back for a second step (a resident
+# batch) and a batch that is planned, stepped once and dropped (every batch of a shuffled training loop) never builds them.
+# MGV_PACKED_ROWS=0: never; =2: from the first step.
+PACKED_ROWS = {'0': 0, '2': 2}.get(os.environ.get('MGV_PACKED_ROWS', '1'), 1)
 
 
-def _sweep_rows(plan):
-    if PACKED_ROWS:
+def _sweep_rows(plan, forward=False):
+    """(pointer, ints per row) of the rows the level kernels read; `forward`: a sweep forward (counts the plan's steps)."""
+    if PACKED_ROWS and forward and plan.__dict__.get('_order_rows') is None:
+        steps = plan.__dict__.get('_sweep_steps', 0)
+        plan._sweep_steps = steps + 1
+        if PACKED_ROWS == 2 or steps >= 1:
+            plan.order_rows                  # (built here, on the step's stream: 0.43 ms once; the first step's backward keeps the span rows)
+    if PACKED_ROWS and plan.__dict__.get('_order_rows') is not None:
         return ptr(plan.order_rows), 32
     return ptr(plan.order_span), 4
 
@@ -792,7 +801,7 @@ class FuncSweepRoundFn(torch.autograd.Function):
         zb = torch.zeros(T, 3 * H, dtype=F32, device=hsd.device)
         hf = hp.clone()                      # never-updated rows keep their state; every updated row is rewritten by its level
         if wpack is not None:
-            _hip.call('mgv_func_sweep_round_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), *_sweep_rows(plan),
+            _hip.call('mgv_func_sweep_round_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), *_sweep_rows(plan, True),
                       ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
                       ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(zb), ptr(ghd), ptr(hp))
         else:
@@ -868,7 +877,7 @@ class FuncSweepFn(torch.autograd.Function):
                       ptr(plan.order_span), ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd),
                       ptr(hf), ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]), ptr(sync), ptr(sticky))
         elif wpack is not None:
-            _hip.call('mgv_func_sweep_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), *_sweep_rows(plan),
+            _hip.call('mgv_func_sweep_fwd_x3', H, N, T, plan.num_levels, ltp, ptr(plan.order), *_sweep_rows(plan, True),
                       ptr(plan.tile_start), ptr(plan.tile_count), ptr(plan.tile_slot), ptr(plan.in_ptr), ptr(plan.in_src), ptr(hsd), ptr(hf),
                       ptr(par[0]), ptr(wpack), ptr(par[2]), ptr(par[3]), ptr(par[4]))
         else:

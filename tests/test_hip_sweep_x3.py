@@ -160,8 +160,9 @@ def test_packed_sweep_rows_and_span_rows_give_the_same_sweep(T, levels, per):
     results = []
     old = ops.PACKED_ROWS
     try:
-        for packed in (True, False):
+        for packed in (2, 0):                # 2: packed rows from a plan's first step on (the default builds them at its second step)
             ops.PACKED_ROWS = packed
+            plan.__dict__.pop('_order_rows', None)
             hs = hs0.clone().requires_grad_(True)
             par = [p.clone().requires_grad_(True) for p in par0]
             hf = ops.FuncSweepFn.apply(plan, hs, *par)
@@ -170,6 +171,20 @@ def test_packed_sweep_rows_and_span_rows_give_the_same_sweep(T, levels, per):
     finally:
         ops.PACKED_ROWS = old
     assert torch.equal(results[0][0], results[1][0])
+    # the default: span rows on a plan's first step, packed rows from its second step on
+    ops.PACKED_ROWS = 1
+    try:
+        plan.__dict__.pop('_order_rows', None)
+        plan.__dict__.pop('_sweep_steps', None)
+        for step in range(2):
+            hs = hs0.clone().requires_grad_(True)
+            par = [p.clone().requires_grad_(True) for p in par0]
+            hf = ops.FuncSweepFn.apply(plan, hs, *par)
+            assert (plan.__dict__.get('_order_rows') is not None) == (step == 1)
+            (hf * ghf).sum().backward()
+            assert torch.equal(hf.detach(), results[0][0])
+    finally:
+        ops.PACKED_ROWS = old
     for name, a, b in zip(['hf', 'd hs', 'd attn_u', 'd Wvc', 'd bvc', 'd bih', 'd bhh'], *results):
         scale = float(b.abs().max())
         assert scale > 0, name
