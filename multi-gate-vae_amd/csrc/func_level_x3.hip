@@ -12,6 +12,10 @@
 //     rows, all of a row's loads in flight together.  8 waves per workgroup, two rows per 16-lane group.
 #include "func_level_x3_common.h"
 
+#ifndef MGV_LVL_FWD_KU
+#define MGV_LVL_FWD_KU 4        // k-steps whose weight fragments the forward requests together (1: four dependent L2 trips per tile; 4: one, 100 VGPRs)
+#endif
+
 namespace mgv {
 
 template <int H, bool HID = false>
@@ -64,7 +68,7 @@ __global__ __launch_bounds__(kLT, 4) void k_level_fwd_x3(LevelX3Args a) {
     lds_barrier();
     STAMP(3);
     f32x4 ar[S::RTW], az[S::RTW], an[S::RTW];
-    lvl_gemm_x3<H>(a.wpack + (int64_t)g * 4 * 6 * H * H, z_hi, z_lo, ar, az, an);
+    lvl_gemm_x3<H, MGV_LVL_FWD_KU>(a.wpack + (int64_t)g * 4 * 6 * H * H, z_hi, z_lo, ar, az, an);
     STAMP(4);
     lds_barrier();                   // s_o overlays the planes
     {

@@ -257,34 +257,45 @@ __device__ __forceinline__ void store_zbar(__bf16* z_hi, __bf16* z_lo, int row, 
     st_bf4(z_hi + row * LDZP + H + 4 * lr, hi); st_bf4(z_lo + row * LDZP + H + 4 * lr, lo);
 }
 
-// gate pre-activations (r, z, n blocks) = zbar[64 x 2H] * Wvc_g^T from the split planes
-template <int H>
+// gate pre-activations (r, z, n blocks) = zbar[64 x 2H] * Wvc_g^T from the split planes.  KU k-steps' weight fragments are requested
+// together (one L2 round trip per KU k-steps: the forward kernel, which has the registers, asks for two at a time; KU = 1 elsewhere)
+template <int H, int KU_ = 1>
 __device__ __forceinline__ void lvl_gemm_x3(const __bf16* wslot, const __bf16* z_hi, const __bf16* z_lo,
                                             f32x4 (&ar)[SplitL<H>::RTW], f32x4 (&az)[SplitL<H>::RTW], f32x4 (&an)[SplitL<H>::RTW]) {
     using S = SplitL<H>;
     constexpr int LDZP = 2 * H + 8, BLK = 6 * H * H, KS = 2 * H / 32;
+    constexpr int KU = (KS % KU_ == 0) ? KU_ : 1;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
     const int wc = w % S::WPC, wr = w / S::WPC;
 #pragma unroll
     for (int i = 0; i < S::RTW; ++i) { ar[i] = f32x4{0.f, 0.f, 0.f, 0.f}; az[i] = ar[i]; an[i] = ar[i]; }
 #pragma unroll 1
-    for (int ks = 0; ks < KS; ++ks) {
-        bf16x8 xh[S::RTW], xl[S::RTW];
+    for (int k0 = 0; k0 < KS; k0 += KU) {
+        bf16x8 bh[KU][3], bl[KU][3];
 #pragma unroll
-        for (int i = 0; i < S::RTW; ++i) {
-            const int off = ((wr * S::RTW + i) * 16 + r) * LDZP + 32 * ks + 8 * q;
-            xh[i] = ldfrag(z_hi + off); xl[i] = ldfrag(z_lo + off);
-        }
+        for (int u = 0; u < KU; ++u)
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
-            const int wo = ((g * (H / 16) + wc) * KS + ks) * 512 + lane * 8;
-            const bf16x8 bh = ldfrag(wslot + wo), bl = ldfrag(wslot + BLK + wo);
+            for (int g = 0; g < 3; ++g) {
+                const int wo = ((g * (H / 16) + wc) * KS + k0 + u) * 512 + lane * 8;
+                bh[u][g] = ldfrag(wslot + wo); bl[u][g] = ldfrag(wslot + BLK + wo);
+            }
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int ks = k0 + u;
+            bf16x8 xh[S::RTW], xl[S::RTW];
 #pragma unroll
             for (int i = 0; i < S::RTW; ++i) {
-                if (g == 0) mma_x3(ar[i], xh[i], xl[i], bh, bl);
-                if (g == 1) mma_x3(az[i], xh[i], xl[i], bh, bl);
-                if (g == 2) mma_x3(an[i], xh[i], xl[i], bh, bl);
+                const int off = ((wr * S::RTW + i) * 16 + r) * LDZP + 32 * ks + 8 * q;
+                xh[i] = ldfrag(z_hi + off); xl[i] = ldfrag(z_lo + off);
             }
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+                for (int i = 0; i < S::RTW; ++i) {
+                    if (g == 0) mma_x3(ar[i], xh[i], xl[i], bh[u][g], bl[u][g]);
+                    if (g == 1) mma_x3(az[i], xh[i], xl[i], bh[u][g], bl[u][g]);
+                    if (g == 2) mma_x3(an[i], xh[i], xl[i], bh[u][g], bl[u][g]);
+                }
         }
     }
 }
